@@ -1,0 +1,199 @@
+/*
+ * pqdecode.h — C ABI of libpqdecode.so: MI355X (gfx950) decoder for uncompressed Parquet
+ * DATA_PAGE (v1) column pages: hybrid RLE/bit-packed levels + PLAIN values.
+ *
+ * This is the boundary a cgo shim binds.  The reference (parsyl/parquet, pure Go) has no FFI;
+ * each entry point below names the reference code it stands in for (paths relative to the
+ * parsyl/parquet module root).  Plain pointers and sizes only; every function returns 0 or a
+ * negative pqd_status and never aborts the process.
+ *
+ * Threading: one pqd_ctx per reader, not used concurrently (the reference reader is single
+ * goroutine).  A ctx may be called from any OS thread; it selects its device on entry.
+ */
+#ifndef PQDECODE_H
+#define PQDECODE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PQD_OK = 0,
+    PQD_E_ARG = -1,         /* bad argument */
+    PQD_E_HIP = -2,         /* HIP runtime error (message in pqd_last_error) */
+    PQD_E_NOMEM = -3,
+    PQD_E_FORMAT = -4,      /* not a Parquet file / thrift decode failed / missing required field */
+    PQD_E_UNSUPPORTED = -5, /* compressed chunk, dictionary page, INT96/FIXED, level width > 8 */
+    PQD_E_CORRUPT = -6,     /* data the reference would fail or panic on (short read, bad run, negative length) */
+    PQD_E_NONCANONICAL = -7 /* bool/string page whose value bytes are not exactly consumed; the
+                               reference would carry the remainder into the next page */
+} pqd_status;
+
+/* Parquet physical types (schema/parquet.thrift Type). */
+enum {
+    PQD_BOOLEAN = 0, PQD_INT32 = 1, PQD_INT64 = 2, PQD_INT96 = 3, PQD_FLOAT = 4, PQD_DOUBLE = 5,
+    PQD_BYTE_ARRAY = 6, PQD_FIXED_LEN_BYTE_ARRAY = 7
+};
+
+/* One column chunk (the reference's parquet.Page, parquet.go:28-34, which despite its name
+ * describes a chunk) plus what the generated Field carries: physical type and max levels
+ * (fields.go:38-57, 147-152). */
+typedef struct {
+    int32_t phys_type;
+    int32_t max_def;     /* 0 → RequiredField.DoRead, >0 → OptionalField.DoRead */
+    int32_t max_rep;
+    int32_t first_page;  /* index into the page array */
+    int32_t n_pages;
+    int32_t column;      /* leaf index in the file schema (informational; set by pqd_file_descriptors) */
+    int64_t num_values;  /* parquet.Page.N: levels in the chunk, nulls included (parquet.go:336) */
+} pqd_chunk_desc;
+
+/* One data page as the reference's page loops see it (fields.go:114-135, 275-317). */
+typedef struct {
+    int64_t src_off;     /* offset of the page payload (first byte after the thrift PageHeader) */
+    int32_t payload_len; /* PageHeader.uncompressed_page_size */
+    int32_t num_values;  /* DataPageHeader.num_values */
+    int32_t rep_bytes;   /* size of the repetition-level block incl. its 4-byte length, 0 if none; -1 = read it from src */
+    int32_t def_bytes;   /* same for definition levels */
+} pqd_page_desc;
+
+/* Which decoded array of a chunk. */
+typedef enum {
+    PQD_OUT_DEFS = 0,         /* uint8[n_levels]  — OptionalField.Defs (fields.go:157, :308) */
+    PQD_OUT_REPS = 1,         /* uint8[n_levels]  — OptionalField.Reps (fields.go:158, :300) */
+    PQD_OUT_VALUES = 2,       /* dense non-null values: LE fixed width, or 1 byte per bool — the f.vals of
+                                 template_required.go:31-33 / template_optional.go:48-50 / parquet.go:455-484 */
+    PQD_OUT_OFFSETS = 3,      /* int32[n_values+1] string offsets into CHARS (template_string.go:47-58) */
+    PQD_OUT_CHARS = 4,        /* concatenated string bytes */
+    PQD_OUT_VALIDITY = 5,     /* bitmap, bit i (LSB first) = (defs[i] == max_def)   (fields.go:220-228 per level) */
+    PQD_OUT_PAGE_NONNULL = 6, /* int64[n_pages] — the `sizes` of DoRead (fields.go:124, :311-312) */
+    PQD_OUT_ROW_LEVEL_OFF = 7,/* int64[n_rows+1] — first level of each row (write_repeated.go:62-80) */
+    PQD_OUT_ROW_VALUE_OFF = 8 /* int64[n_rows+1] — first value of each row */
+} pqd_output;
+
+typedef struct {
+    int64_t n_levels;   /* entries in DEFS (and REPS when max_rep > 0) */
+    int64_t n_values;   /* non-null values (required chunk: num_values) */
+    int64_t value_bytes;/* bytes in VALUES (fixed width: n_values*w; bool: n_values; string: 0) */
+    int64_t chars_bytes;/* bytes in CHARS */
+    int64_t n_rows;     /* rows spanned by the chunk (entries-1 of the row offset arrays) */
+    int64_t n_pages;
+} pqd_chunk_info;
+
+typedef struct pqd_ctx pqd_ctx;
+typedef struct pqd_plan pqd_plan;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int pqd_create(int device, pqd_ctx** out);
+void pqd_destroy(pqd_ctx* ctx);
+const char* pqd_last_error(pqd_ctx* ctx);
+
+/* Pinned host staging owned by the library, so a Go caller never hands the library a Go pointer
+ * that outlives the call. */
+void* pqd_host_alloc(pqd_ctx* ctx, size_t bytes);
+void pqd_host_free(pqd_ctx* ctx, void* p);
+/* Device buffer for file bytes (device-resident path). */
+void* pqd_device_alloc(pqd_ctx* ctx, size_t bytes);
+void pqd_device_free(pqd_ctx* ctx, void* p);
+int pqd_copy_to_device(pqd_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+
+/* ---- decode: replaces the bodies of the six generated Field.Read methods -------------------
+ * (cmd/parquetgen/gen/template_required.go:25-35, template_optional.go:42-52, template_string.go:41-60,
+ *  template_string_optional.go:62-81, template_bool.go:38-46, template_bool_optional.go:24-33)
+ * together with RequiredField/OptionalField.DoRead (fields.go:114-135, 275-317), readLevels
+ * (fields.go:448-457), rle.Read (internal/rle/rle.go:159-290), bitpack.Unpack
+ * (internal/bitpack/bitpack.go:76-141) and GetBools (parquet.go:455-505), for a whole batch of
+ * column chunks — normally every chunk of one or more row groups, i.e. one readRowGroup
+ * (template.go:320-351) per call.
+ *
+ * pqd_plan_create does the host-side part: validates the descriptors, reads the level-block
+ * lengths (rep_bytes/def_bytes == -1) from `src_host`, sizes the outputs and uploads the tables.
+ * `src_host` may be NULL when every page carries rep_bytes/def_bytes.  `src_len` is the length of
+ * the byte range the page offsets index into.
+ */
+int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
+                    const pqd_page_desc* pages, size_t n_pages,
+                    const void* src_host, size_t src_len, pqd_plan** out);
+void pqd_plan_destroy(pqd_plan* plan);
+
+/* Runs the decode kernels over `src_device` (device pointer to the same `src_len` bytes the plan was
+ * built for).  Asynchronous on the ctx stream; outputs stay in HBM.  May be called repeatedly. */
+int pqd_plan_run(pqd_plan* plan, const void* src_device);
+/* Waits for the last run and returns its status (PQD_OK or the first decode error). */
+int pqd_plan_sync(pqd_plan* plan);
+/* Device time of the last completed run in milliseconds (first kernel start → last kernel end),
+ * and of its dominant kernel (the PLAIN value gather), both from HIP events on the ctx stream. */
+int pqd_plan_last_ms(pqd_plan* plan, float* total_ms, float* plain_copy_ms);
+/* Algorithmic bytes of one run: payload bytes read + decoded bytes the reference materialises
+ * (defs, reps, values / bools / string offsets+chars); and the part moved by the value gather. */
+int pqd_plan_bytes(pqd_plan* plan, int64_t* bytes_in, int64_t* bytes_out, int64_t* plain_copy_bytes);
+
+/* Results of the last synced run. */
+int pqd_plan_chunk_info(pqd_plan* plan, size_t chunk, pqd_chunk_info* info);
+const void* pqd_plan_device_ptr(pqd_plan* plan, size_t chunk, pqd_output which);
+/* Copies an output array to host memory; `cap` is the size of `dst` in bytes. Returns bytes copied
+ * (>= 0) or a negative status. */
+int64_t pqd_plan_fetch(pqd_plan* plan, size_t chunk, pqd_output which, void* dst, size_t cap);
+
+/* Convenience: host buffer in, results on device; = copy_to_device + plan_create + run + sync.
+ * The plan owns the device copy of `src`. */
+int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
+               const pqd_page_desc* pages, size_t n_pages,
+               const void* src_host, size_t src_len, pqd_plan** out);
+
+/* ---- standalone level decode: rle.Read (internal/rle/rle.go:159-195) for one block ----------
+ * `block` = int32 LE length + runs, in host memory.  width 0..32; out_elem_size 1 (width <= 8),
+ * 2 (<= 16) or 4.  Decodes at most `max_values` values into `out_host`; *n_decoded receives the
+ * number the block holds (bit-packed tails count in full, as in the reference). */
+int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block, size_t block_len,
+                   int out_elem_size, void* out_host, size_t max_values, int64_t* n_decoded);
+
+/* ---- file walk: the host-side prerequisite (parquet.go:349-378 ReadMetaData/PageHeader,
+ * parquet.go:322-346 Pages, template.go:320-351 readRowGroup's chunk order) ------------------- */
+typedef struct pqd_file pqd_file;
+
+typedef struct {
+    int32_t phys_type;
+    int32_t converted_type; /* -1 if absent */
+    int32_t max_def;
+    int32_t max_rep;
+    int32_t leaf_repetition; /* 0 required, 1 optional, 2 repeated */
+    int32_t reserved;
+} pqd_column_info;
+
+/* Parses the footer and walks every page header of every column chunk sequentially from byte 4,
+ * exactly as the reference reader consumes the file (it never seeks: template.go:263). */
+int pqd_file_open(const void* buf, size_t len, pqd_file** out, char* err, size_t err_cap);
+void pqd_file_close(pqd_file* f);
+int64_t pqd_file_num_rows(const pqd_file* f);
+int32_t pqd_file_num_columns(const pqd_file* f);
+int32_t pqd_file_num_row_groups(const pqd_file* f);
+int64_t pqd_file_row_group_rows(const pqd_file* f, int32_t rg);
+int pqd_file_column(const pqd_file* f, int32_t col, pqd_column_info* info);
+const char* pqd_file_column_path(const pqd_file* f, int32_t col); /* dotted, as Field.Name() */
+/* Chunk and page descriptors of row groups [rg_first, rg_first+rg_count); chunk c of row group g
+ * is entry (g-rg_first)*num_columns + c.  The returned arrays belong to the file object and stay
+ * valid until the next call or pqd_file_close. */
+int pqd_file_descriptors(pqd_file* f, int32_t rg_first, int32_t rg_count,
+                         const pqd_chunk_desc** chunks, size_t* n_chunks,
+                         const pqd_page_desc** pages, size_t* n_pages);
+/* Total page headers walked (the reference's PageHeaders, parquet.go:382-394). */
+int64_t pqd_file_num_pages(const pqd_file* f);
+/* One walked page header, the equivalent of `parquetgen -pageheaders` (cmd/parquetgen/main.go:51-80):
+ * out = {type, uncompressed_page_size, compressed_page_size, num_values, encoding,
+ *        definition_level_encoding, repetition_level_encoding, header length in bytes}. */
+int pqd_file_page_header(const pqd_file* f, int64_t page, int32_t out[8], int64_t* header_pos);
+/* CompressionCodec of a column chunk (0 = UNCOMPRESSED; others are walked but not decoded). */
+int pqd_file_chunk_codec(const pqd_file* f, int32_t rg, int32_t chunk);
+/* What Metadata.Pages (parquet.go:322-346) hands the Field for one chunk, plus where the walk found it:
+ * out = {leaf column index, ColumnMetaData.num_values (Page.N), total_compressed_size (Page.Size),
+ *        file position of the chunk's first page header, index of its first walked page, pages walked}. */
+int pqd_file_chunk_meta(const pqd_file* f, int32_t rg, int32_t chunk, int64_t out[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQDECODE_H */

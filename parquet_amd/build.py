@@ -1,0 +1,45 @@
+"""Builds the native libraries in-tree (parquet_amd/lib/*.so) for gfx950.
+
+hipcc cross-compiles without a GPU, so this also runs in a CPU-only container.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib")
+
+DECODE_SOURCES = ["pqd_kernels.hip", "pqd_api.cpp", "pqd_file.cpp"]
+DECODE_DEPS = DECODE_SOURCES + ["pqd_device.h", "thrift_compact.h", os.path.join("..", "..", "include", "pqdecode.h")]
+SYNTH_SOURCES = ["pqd_writer.cpp"]
+SYNTH_DEPS = SYNTH_SOURCES + ["thrift_compact.h"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in deps)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+
+
+def build_all(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    decode = os.path.join(LIB, "libpqdecode.so")
+    if force or _stale(decode, DECODE_DEPS):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+              "-Wno-unused-function", "-o", decode] + DECODE_SOURCES)
+    synth = os.path.join(LIB, "libpqsynth.so")
+    if force or _stale(synth, SYNTH_DEPS):
+        _run([os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", synth] + SYNTH_SOURCES)
+    return decode, synth
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,731 @@
+// C ABI of libpqdecode.so (see include/pqdecode.h): context, decode plans, result access.
+// The host side here only plans (descriptor validation, table building, output sizing) and
+// launches; every byte of decode work happens in the kernels of pqd_kernels.hip.  There is no CPU
+// decode path: without a working HIP device every entry point that needs one fails with PQD_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pqdecode.h"
+#include "pqd_device.h"
+
+using namespace pqd;
+
+struct pqd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    u32 copy_grid = 2048;
+};
+
+namespace {
+
+int bits_len(unsigned v) { int n = 0; while (v) { n++; v >>= 1; } return n; }  // math/bits.Len
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int fail(pqd_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        ctx->err = what;
+        if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((ctx), PQD_E_HIP, #call, e_); } while (0)
+
+struct OutPtrs { u8* p[9]; size_t cap[9]; };
+
+}  // namespace
+
+struct pqd_plan {
+    pqd_ctx* ctx = nullptr;
+    size_t src_len = 0;
+    u8* owned_src = nullptr;       // device copy made by pqd_decode
+    const u8* last_src = nullptr;
+
+    // host copies of the tables
+    std::vector<ChunkRec> chunks;
+    std::vector<PageRec> pages;
+    std::vector<Region> lregions, sregions;
+    std::vector<u32> ltile_prefix, lotile_prefix, stile_chain_prefix;
+    std::vector<Seg> segs;
+    std::vector<u32> seg_blk_prefix;
+    std::vector<u32> bool_pages, btile_prefix, str_pages, stile_prefix, row_chunks, rtile_prefix;
+    std::vector<OutPtrs> outs;
+    std::vector<int> chunk_width;
+
+    // device
+    u8* arena = nullptr;
+    size_t arena_bytes = 0;
+    ChunkRec* d_chunks = nullptr; PageRec* d_pages = nullptr;
+    Region *d_lregions = nullptr, *d_sregions = nullptr;
+    u32 *d_ltile_prefix = nullptr, *d_lotile_prefix = nullptr, *d_stile_chain_prefix = nullptr;
+    Seg* d_segs = nullptr; u32* d_seg_blk_prefix = nullptr;
+    u32 *d_bool_pages = nullptr, *d_btile_prefix = nullptr, *d_str_pages = nullptr, *d_stile_prefix = nullptr;
+    u32 *d_row_chunks = nullptr, *d_rtile_prefix = nullptr;
+    ExitRec *d_lexit = nullptr, *d_sexit = nullptr;
+    TileEntry *d_ltile_entry = nullptr, *d_stile_entry = nullptr;
+    RegionTotal *d_ltotals = nullptr, *d_stotals = nullptr;
+    RunRec* d_runs = nullptr; u32* d_otile_first = nullptr;
+    PageDyn* d_page_dyn = nullptr; ChunkDyn* d_chunk_dyn = nullptr; RowTile* d_row_tiles = nullptr;
+    int* d_status = nullptr;
+    u8 *ff_begin = nullptr, *zero_begin = nullptr;  // per-run reset ranges
+    size_t ff_bytes = 0, zero_bytes = 0;
+
+    u32 n_ltiles = 0, n_lotiles = 0, n_stiles_chain = 0, n_btiles = 0, n_stiles = 0, n_rtiles = 0, n_copy_blocks = 0;
+    int64_t bytes_in = 0, copy_bytes = 0;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evc0 = nullptr, evc1 = nullptr;
+    bool ran = false, synced = false;
+    int last_status = 0;
+    std::vector<ChunkDyn> h_chunk_dyn;
+    int h_status[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+struct ArenaPlan {
+    size_t total = 0;
+    size_t take(size_t bytes) { size_t o = total; total += align_up(bytes ? bytes : 1, 256); return o; }
+};
+
+template <class T>
+int upload(pqd_ctx* ctx, T* dst, const std::vector<T>& v) {
+    if (v.empty()) return PQD_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return PQD_OK;
+}
+
+int map_status(int st) {
+    switch (st) {
+    case 0: return PQD_OK;
+    case ST_CORRUPT: return PQD_E_CORRUPT;
+    case ST_NONCANONICAL: return PQD_E_NONCANONICAL;
+    default: return PQD_E_UNSUPPORTED;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pqd_create(int device, pqd_ctx** out) {
+    if (!out) return PQD_E_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || device < 0 || device >= n) return PQD_E_HIP;
+    pqd_ctx* ctx = new pqd_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return PQD_E_HIP;
+    }
+    const char* g = getenv("PQD_COPY_GRID");
+    if (g && atoi(g) > 0) ctx->copy_grid = (u32)atoi(g);
+    *out = ctx;
+    return PQD_OK;
+}
+
+void pqd_destroy(pqd_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* pqd_last_error(pqd_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+void* pqd_host_alloc(pqd_ctx* ctx, size_t bytes) {
+    if (!ctx) return nullptr;
+    void* p = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+        return nullptr;
+    return p;
+}
+void pqd_host_free(pqd_ctx* ctx, void* p) { if (ctx && p) (void)hipHostFree(p); }
+
+void* pqd_device_alloc(pqd_ctx* ctx, size_t bytes) {
+    if (!ctx) return nullptr;
+    void* p = nullptr;
+    // 64 bytes of slack: the kernels read whole 8/16-byte words that may straddle the last payload byte
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&p, bytes + 64) != hipSuccess) return nullptr;
+    return p;
+}
+void pqd_device_free(pqd_ctx* ctx, void* p) { if (ctx && p) { (void)hipSetDevice(ctx->device); (void)hipFree(p); } }
+
+int pqd_copy_to_device(pqd_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || !dst || !src) return PQD_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PQD_OK;
+}
+
+void pqd_plan_destroy(pqd_plan* pl) {
+    if (!pl) return;
+    (void)hipSetDevice(pl->ctx->device);
+    (void)hipStreamSynchronize(pl->ctx->stream);
+    if (pl->arena) (void)hipFree(pl->arena);
+    if (pl->owned_src) (void)hipFree(pl->owned_src);
+    if (pl->ev0) (void)hipEventDestroy(pl->ev0);
+    if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+    if (pl->evc0) (void)hipEventDestroy(pl->evc0);
+    if (pl->evc1) (void)hipEventDestroy(pl->evc1);
+    delete pl;
+}
+
+int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks, const pqd_page_desc* pages,
+                    size_t n_pages, const void* src_host_, size_t src_len, pqd_plan** out) {
+    if (!ctx || !out || (!chunks && n_chunks) || (!pages && n_pages)) return PQD_E_ARG;
+    if (n_chunks > 0x7fffffffu || n_pages > 0x7fffffffu) return fail(ctx, PQD_E_ARG, "too many chunks or pages");
+    const u8* src_host = (const u8*)src_host_;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pqd_plan* pl = new pqd_plan();
+    pl->ctx = ctx;
+    pl->src_len = src_len;
+    struct Guard { pqd_plan* p; ~Guard() { if (p) pqd_plan_destroy(p); } } guard{pl};
+
+    pl->chunks.resize(n_chunks);
+    pl->pages.resize(n_pages);
+    pl->chunk_width.resize(n_chunks);
+    std::vector<u32> rep_bytes(n_pages, 0), def_bytes(n_pages, 0);
+    std::vector<u64> lvl_off(n_pages, 0), val_stream_off(n_pages, 0), payload_off(n_pages, 0);
+    std::vector<char> page_seen(n_pages, 0);
+
+    // ---- validate descriptors; locate the level blocks and the values region of every page
+    for (size_t c = 0; c < n_chunks; c++) {
+        const pqd_chunk_desc& cd = chunks[c];
+        ChunkRec& C = pl->chunks[c];
+        memset(&C, 0, sizeof C);
+        int w = 0;
+        switch (cd.phys_type) {
+        case PQD_INT32: case PQD_FLOAT: w = 4; break;
+        case PQD_INT64: case PQD_DOUBLE: w = 8; break;
+        case PQD_BOOLEAN: case PQD_BYTE_ARRAY: break;
+        default: return fail(ctx, PQD_E_UNSUPPORTED, "unsupported physical type");
+        }
+        if (cd.max_def < 0 || cd.max_def > 255 || cd.max_rep < 0 || cd.max_rep > 255 || cd.max_rep > cd.max_def)
+            return fail(ctx, PQD_E_UNSUPPORTED, "max levels out of range");
+        if (cd.first_page < 0 || cd.n_pages < 0 || (size_t)cd.first_page + (size_t)cd.n_pages > n_pages || cd.num_values < 0)
+            return fail(ctx, PQD_E_ARG, "chunk page range out of bounds");
+        C.phys_type = cd.phys_type; C.max_def = cd.max_def; C.max_rep = cd.max_rep;
+        C.width_bytes = (u32)w;
+        C.first_page = (u32)cd.first_page; C.n_pages = (u32)cd.n_pages;
+        pl->chunk_width[c] = w;
+        u64 levels = 0, stream = 0;
+        for (int k = 0; k < cd.n_pages; k++) {
+            const size_t pi = (size_t)cd.first_page + k;
+            if (page_seen[pi]) return fail(ctx, PQD_E_ARG, "page belongs to two chunks");
+            page_seen[pi] = 1;
+            const pqd_page_desc& pd = pages[pi];
+            if (pd.src_off < 0 || pd.payload_len < 0 || pd.num_values < 0 ||
+                (u64)pd.src_off + (u64)pd.payload_len > src_len)
+                return fail(ctx, PQD_E_CORRUPT, "page payload outside the source buffer");
+            u64 l = 0;
+            for (int lv = 0; lv < 2; lv++) {
+                const bool present = lv == 0 ? cd.max_rep > 0 : cd.max_def > 0;
+                if (!present) continue;
+                int32_t given = lv == 0 ? pd.rep_bytes : pd.def_bytes;
+                if (given < 0) {
+                    // int32 LE block length in front of the runs (rle.go:161-164)
+                    if (!src_host) return fail(ctx, PQD_E_ARG, "level block sizes unknown and no host source given");
+                    if (l + 4 > (u64)pd.payload_len) return fail(ctx, PQD_E_CORRUPT, "level block length outside the page");
+                    int32_t len;
+                    memcpy(&len, src_host + pd.src_off + l, 4);
+                    if (len < 0) return fail(ctx, PQD_E_CORRUPT, "negative level block length");
+                    given = (int32_t)((int64_t)len + 4 > 0x7fffffff ? 0x7fffffff : len + 4);
+                }
+                if (given < 4 || l + (u64)given > (u64)pd.payload_len)
+                    return fail(ctx, PQD_E_CORRUPT, "level block runs past the page payload");
+                (lv == 0 ? rep_bytes[pi] : def_bytes[pi]) = (u32)given;
+                l += (u64)given;
+            }
+            PageRec& P = pl->pages[pi];
+            P.val_src_off = (u64)pd.src_off + l;
+            P.val_len = (u32)((u64)pd.payload_len - l);
+            P.num_values = (u32)pd.num_values;
+            P.chunk = (u32)c;
+            P.pad = 0;
+            payload_off[pi] = (u64)pd.src_off;
+            lvl_off[pi] = levels;
+            val_stream_off[pi] = stream;
+            levels += (u64)pd.num_values;
+            stream += P.val_len;
+            pl->bytes_in += pd.payload_len;
+        }
+        C.n_levels = levels;
+        C.stream_len = stream;
+        C.req_values = (u64)cd.num_values;
+        if (cd.max_def == 0) {
+            // RequiredField.DoRead stops once sum(NumValues) >= pg.N (fields.go:118); the typed Read then
+            // takes pg.N values.  For bools and strings the page split matters, so require an exact fit.
+            if (levels < (u64)cd.num_values) return fail(ctx, PQD_E_CORRUPT, "pages hold fewer values than the chunk declares");
+            if (w == 0 && levels != (u64)cd.num_values) return fail(ctx, PQD_E_NONCANONICAL, "page value counts exceed the chunk's");
+        }
+        if (bits_len((unsigned)cd.max_def) > 8) return fail(ctx, PQD_E_UNSUPPORTED, "level width > 8");
+    }
+    for (size_t p = 0; p < n_pages; p++)
+        if (!page_seen[p]) return fail(ctx, PQD_E_ARG, "page not owned by any chunk");
+
+    // ---- size the outputs and the scratch tables
+    ArenaPlan ap;
+    std::vector<size_t> off_out(n_chunks * 9, (size_t)-1);
+    pl->outs.resize(n_chunks);
+    for (size_t c = 0; c < n_chunks; c++) {
+        const ChunkRec& C = pl->chunks[c];
+        size_t* o = &off_out[c * 9];
+        size_t* cap = pl->outs[c].cap;
+        memset(cap, 0, sizeof pl->outs[c].cap);
+        auto want = [&](int which, size_t bytes) { cap[which] = bytes; o[which] = ap.take(bytes + 64); };
+        if (C.max_def > 0) {
+            want(PQD_OUT_DEFS, C.n_levels);
+            want(PQD_OUT_VALIDITY, (C.n_levels + 7) / 8);
+            want(PQD_OUT_ROW_LEVEL_OFF, (C.n_levels + 1) * 8);
+            want(PQD_OUT_ROW_VALUE_OFF, (C.n_levels + 1) * 8);
+        }
+        if (C.max_rep > 0) want(PQD_OUT_REPS, C.n_levels);
+        if (C.width_bytes) want(PQD_OUT_VALUES, C.stream_len);
+        else if (C.phys_type == PQD_BOOLEAN) want(PQD_OUT_VALUES, C.n_levels);
+        else {
+            want(PQD_OUT_OFFSETS, (C.n_levels + 1) * 4);
+            want(PQD_OUT_CHARS, C.stream_len);
+        }
+        want(PQD_OUT_PAGE_NONNULL, (size_t)C.n_pages * 8);
+    }
+
+    // regions
+    u64 run_base = 0;
+    pl->ltile_prefix.push_back(0);
+    pl->lotile_prefix.push_back(0);
+    pl->stile_chain_prefix.push_back(0);
+    pl->btile_prefix.push_back(0);
+    pl->stile_prefix.push_back(0);
+    pl->rtile_prefix.push_back(0);
+    pl->seg_blk_prefix.push_back(0);
+    auto push_prefix = [&](std::vector<u32>& v, u64 add, bool& ovf) {
+        u64 nv = (u64)v.back() + add;
+        if (nv > 0x7fffffffull) ovf = true;
+        v.push_back((u32)nv);
+    };
+    bool ovf = false;
+    for (size_t c = 0; c < n_chunks; c++) {
+        const ChunkRec& C = pl->chunks[c];
+        for (u32 k = 0; k < C.n_pages; k++) {
+            const u32 pi = C.first_page + k;
+            const PageRec& P = pl->pages[pi];
+            u64 l = 0;
+            for (int lv = 0; lv < 2; lv++) {
+                const u32 nb = lv == 0 ? rep_bytes[pi] : def_bytes[pi];
+                if (!nb) continue;
+                Region R;
+                memset(&R, 0, sizeof R);
+                R.src_off = payload_off[pi] + l + 4;
+                R.len = nb - 4;
+                R.width = (u32)bits_len((unsigned)(lv == 0 ? C.max_rep : C.max_def));
+                R.tile_base = pl->ltile_prefix.back();
+                R.otile_base = pl->lotile_prefix.back();
+                R.run_base = run_base;
+                R.n_out = P.num_values;
+                R.out = (u8*)(uintptr_t)lvl_off[pi];  // patched with the array base below
+                R.page = pi;
+                R.count_level = lv == 1 ? (u32)C.max_def : ERR_POS;
+                pl->lregions.push_back(R);
+                push_prefix(pl->ltile_prefix, (R.len + CH_T - 1) / CH_T, ovf);
+                push_prefix(pl->lotile_prefix, ((u64)P.num_values + OT - 1) / OT, ovf);
+                run_base += R.len;
+                l += nb;
+            }
+            if (C.phys_type == PQD_BYTE_ARRAY) {
+                Region R;
+                memset(&R, 0, sizeof R);
+                R.src_off = P.val_src_off;
+                R.len = P.val_len;
+                R.tile_base = pl->stile_chain_prefix.back();
+                R.n_out = P.num_values;
+                R.page = pi;
+                R.count_level = ERR_POS;
+                pl->sregions.push_back(R);
+                push_prefix(pl->stile_chain_prefix, ((u64)P.val_len + CH_T - 1) / CH_T, ovf);
+                pl->str_pages.push_back(pi);
+                push_prefix(pl->stile_prefix, ((u64)P.val_len + ST - 1) / ST, ovf);
+            } else if (C.phys_type == PQD_BOOLEAN) {
+                pl->bool_pages.push_back(pi);
+                push_prefix(pl->btile_prefix, ((u64)P.num_values + BT - 1) / BT, ovf);
+            }
+        }
+        if (C.max_def > 0) {
+            pl->row_chunks.push_back((u32)c);
+            push_prefix(pl->rtile_prefix, (C.n_levels + RT - 1) / RT, ovf);
+        }
+    }
+    if (ovf) return fail(ctx, PQD_E_UNSUPPORTED, "batch too large for 32-bit tile indices");
+    pl->n_ltiles = pl->ltile_prefix.back();
+    pl->n_lotiles = pl->lotile_prefix.back();
+    pl->n_stiles_chain = pl->stile_chain_prefix.back();
+    pl->n_btiles = pl->btile_prefix.back();
+    pl->n_stiles = pl->stile_prefix.back();
+    pl->n_rtiles = pl->rtile_prefix.back();
+
+    // static tables
+    const size_t o_chunks = ap.take(n_chunks * sizeof(ChunkRec));
+    const size_t o_pages = ap.take(n_pages * sizeof(PageRec));
+    const size_t o_lreg = ap.take(pl->lregions.size() * sizeof(Region));
+    const size_t o_sreg = ap.take(pl->sregions.size() * sizeof(Region));
+    const size_t o_ltp = ap.take(pl->ltile_prefix.size() * 4);
+    const size_t o_lotp = ap.take(pl->lotile_prefix.size() * 4);
+    const size_t o_sctp = ap.take(pl->stile_chain_prefix.size() * 4);
+    const size_t o_bp = ap.take(pl->bool_pages.size() * 4);
+    const size_t o_btp = ap.take(pl->btile_prefix.size() * 4);
+    const size_t o_sp = ap.take(pl->str_pages.size() * 4);
+    const size_t o_stp = ap.take(pl->stile_prefix.size() * 4);
+    const size_t o_rc = ap.take(pl->row_chunks.size() * 4);
+    const size_t o_rtp = ap.take(pl->rtile_prefix.size() * 4);
+    // scratch
+    const size_t o_lexit = ap.take((size_t)pl->n_ltiles * CH_E_LEVELS * sizeof(ExitRec));
+    const size_t o_sexit = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * sizeof(ExitRec));
+    const size_t o_ltot = ap.take(pl->lregions.size() * sizeof(RegionTotal));
+    const size_t o_stot = ap.take(pl->sregions.size() * sizeof(RegionTotal));
+    const size_t o_runs = ap.take((size_t)run_base * sizeof(RunRec));
+    const size_t o_rtiles = ap.take((size_t)pl->n_rtiles * sizeof(RowTile));
+    const size_t o_cdyn = ap.take(n_chunks * sizeof(ChunkDyn));
+    // reset to 0xFF every run
+    const size_t o_ff = ap.total;
+    const size_t o_lte = ap.take((size_t)pl->n_ltiles * sizeof(TileEntry));
+    const size_t o_ste = ap.take((size_t)pl->n_stiles_chain * sizeof(TileEntry));
+    const size_t o_otf = ap.take((size_t)pl->n_lotiles * 4);
+    const size_t ff_end = ap.total;
+    // reset to 0 every run
+    const size_t o_zero = ap.total;
+    const size_t o_pdyn = ap.take(n_pages * sizeof(PageDyn));
+    const size_t o_status = ap.take(16);
+    const size_t zero_end = ap.total;
+    // the copy segment tables depend on output addresses → placed last, sized now
+    size_t n_segs = 0;
+    for (size_t c = 0; c < n_chunks; c++)
+        if (pl->chunks[c].width_bytes)
+            for (u32 k = 0; k < pl->chunks[c].n_pages; k++) n_segs += pl->pages[pl->chunks[c].first_page + k].val_len > 0;
+    const size_t o_segs = ap.take(n_segs * sizeof(Seg));
+    const size_t o_segp = ap.take((n_segs + 1) * 4);
+
+    pl->arena_bytes = ap.total;
+    hipError_t e = hipMalloc((void**)&pl->arena, pl->arena_bytes);
+    if (e != hipSuccess) return fail(ctx, PQD_E_NOMEM, "hipMalloc of the plan arena failed", e);
+    u8* A = pl->arena;
+
+    // patch pointers
+    for (size_t c = 0; c < n_chunks; c++) {
+        ChunkRec& C = pl->chunks[c];
+        u8** ptrs[9] = {&C.defs, &C.reps, &C.values, &C.offsets, &C.chars, &C.validity, &C.page_nonnull,
+                        &C.row_level_off, &C.row_value_off};
+        for (int w = 0; w < 9; w++) {
+            const size_t o = off_out[c * 9 + w];
+            *ptrs[w] = o == (size_t)-1 ? nullptr : A + o;
+            pl->outs[c].p[w] = *ptrs[w];
+        }
+    }
+    for (Region& R : pl->lregions) {
+        const ChunkRec& C = pl->chunks[pl->pages[R.page].chunk];
+        const u64 lo = (u64)(uintptr_t)R.out;
+        R.out = (R.count_level == ERR_POS ? C.reps : C.defs) + lo;
+    }
+    for (Region& R : pl->sregions) R.out = pl->chunks[pl->pages[R.page].chunk].offsets;
+
+    // PLAIN value segments: the concatenation of the pages' values regions (fields.go:131,313)
+    for (size_t c = 0; c < n_chunks; c++) {
+        const ChunkRec& C = pl->chunks[c];
+        if (!C.width_bytes) continue;
+        for (u32 k = 0; k < C.n_pages; k++) {
+            const u32 pi = C.first_page + k;
+            const PageRec& P = pl->pages[pi];
+            if (!P.val_len) continue;
+            Seg s;
+            s.src_off = P.val_src_off;
+            s.dst = C.values + val_stream_off[pi];
+            s.len = P.val_len;
+            pl->segs.push_back(s);
+            const u64 a = (u64)(uintptr_t)s.dst & 15;
+            bool o2 = false;
+            push_prefix(pl->seg_blk_prefix, (a + s.len + CP_BLK - 1) / CP_BLK, o2);
+            if (o2) return fail(ctx, PQD_E_UNSUPPORTED, "batch too large for 32-bit block indices");
+            pl->copy_bytes += 2 * (int64_t)s.len;
+        }
+    }
+    pl->n_copy_blocks = pl->seg_blk_prefix.back();
+
+    pl->d_chunks = (ChunkRec*)(A + o_chunks); pl->d_pages = (PageRec*)(A + o_pages);
+    pl->d_lregions = (Region*)(A + o_lreg); pl->d_sregions = (Region*)(A + o_sreg);
+    pl->d_ltile_prefix = (u32*)(A + o_ltp); pl->d_lotile_prefix = (u32*)(A + o_lotp);
+    pl->d_stile_chain_prefix = (u32*)(A + o_sctp);
+    pl->d_bool_pages = (u32*)(A + o_bp); pl->d_btile_prefix = (u32*)(A + o_btp);
+    pl->d_str_pages = (u32*)(A + o_sp); pl->d_stile_prefix = (u32*)(A + o_stp);
+    pl->d_row_chunks = (u32*)(A + o_rc); pl->d_rtile_prefix = (u32*)(A + o_rtp);
+    pl->d_lexit = (ExitRec*)(A + o_lexit); pl->d_sexit = (ExitRec*)(A + o_sexit);
+    pl->d_ltotals = (RegionTotal*)(A + o_ltot); pl->d_stotals = (RegionTotal*)(A + o_stot);
+    pl->d_runs = (RunRec*)(A + o_runs); pl->d_row_tiles = (RowTile*)(A + o_rtiles);
+    pl->d_chunk_dyn = (ChunkDyn*)(A + o_cdyn);
+    pl->d_ltile_entry = (TileEntry*)(A + o_lte); pl->d_stile_entry = (TileEntry*)(A + o_ste);
+    pl->d_otile_first = (u32*)(A + o_otf);
+    pl->d_page_dyn = (PageDyn*)(A + o_pdyn); pl->d_status = (int*)(A + o_status);
+    pl->d_segs = (Seg*)(A + o_segs); pl->d_seg_blk_prefix = (u32*)(A + o_segp);
+    pl->ff_begin = A + o_ff; pl->ff_bytes = ff_end - o_ff;
+    pl->zero_begin = A + o_zero; pl->zero_bytes = zero_end - o_zero;
+
+    int rc;
+    if ((rc = upload(ctx, pl->d_chunks, pl->chunks))) return rc;
+    if ((rc = upload(ctx, pl->d_pages, pl->pages))) return rc;
+    if ((rc = upload(ctx, pl->d_lregions, pl->lregions))) return rc;
+    if ((rc = upload(ctx, pl->d_sregions, pl->sregions))) return rc;
+    if ((rc = upload(ctx, pl->d_ltile_prefix, pl->ltile_prefix))) return rc;
+    if ((rc = upload(ctx, pl->d_lotile_prefix, pl->lotile_prefix))) return rc;
+    if ((rc = upload(ctx, pl->d_stile_chain_prefix, pl->stile_chain_prefix))) return rc;
+    if ((rc = upload(ctx, pl->d_bool_pages, pl->bool_pages))) return rc;
+    if ((rc = upload(ctx, pl->d_btile_prefix, pl->btile_prefix))) return rc;
+    if ((rc = upload(ctx, pl->d_str_pages, pl->str_pages))) return rc;
+    if ((rc = upload(ctx, pl->d_stile_prefix, pl->stile_prefix))) return rc;
+    if ((rc = upload(ctx, pl->d_row_chunks, pl->row_chunks))) return rc;
+    if ((rc = upload(ctx, pl->d_rtile_prefix, pl->rtile_prefix))) return rc;
+    if ((rc = upload(ctx, pl->d_segs, pl->segs))) return rc;
+    if ((rc = upload(ctx, pl->d_seg_blk_prefix, pl->seg_blk_prefix))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipEventCreate(&pl->ev0));
+    HIP_TRY(ctx, hipEventCreate(&pl->ev1));
+    HIP_TRY(ctx, hipEventCreate(&pl->evc0));
+    HIP_TRY(ctx, hipEventCreate(&pl->evc1));
+    pl->h_chunk_dyn.resize(n_chunks);
+    guard.p = nullptr;
+    *out = pl;
+    return PQD_OK;
+}
+
+int pqd_plan_run(pqd_plan* pl, const void* src_device) {
+    if (!pl || !src_device) return PQD_E_ARG;
+    pqd_ctx* ctx = pl->ctx;
+    hipStream_t st = ctx->stream;
+    const u8* src = (const u8*)src_device;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const u32 n_chunks = (u32)pl->chunks.size(), n_pages = (u32)pl->pages.size();
+    const u32 n_lreg = (u32)pl->lregions.size(), n_sreg = (u32)pl->sregions.size();
+    pl->last_src = src;
+    pl->synced = false;
+    HIP_TRY(ctx, hipEventRecord(pl->ev0, st));
+    if (pl->ff_bytes) HIP_TRY(ctx, hipMemsetAsync(pl->ff_begin, 0xFF, pl->ff_bytes, st));
+    HIP_TRY(ctx, hipMemsetAsync(pl->zero_begin, 0, pl->zero_bytes, st));
+
+    // PLAIN fixed-width values: independent of the levels (the reference reads the concatenated
+    // values regions as one stream)
+    HIP_TRY(ctx, hipEventRecord(pl->evc0, st));
+    HIP_TRY(ctx, launch_copy(st, src, pl->d_segs, pl->d_seg_blk_prefix, (u32)pl->segs.size(), pl->n_copy_blocks, ctx->copy_grid));
+    HIP_TRY(ctx, hipEventRecord(pl->evc1, st));
+
+    // levels
+    if (n_lreg) {
+        HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, src, pl->d_lregions, pl->d_ltile_prefix, n_lreg, pl->n_ltiles, pl->d_lexit,
+                                  pl->d_ltile_entry, pl->d_ltotals, pl->d_runs, pl->d_otile_first, pl->d_page_dyn, pl->d_status, 0));
+        HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, src, pl->d_lregions, pl->d_ltile_prefix, n_lreg, pl->n_ltiles, pl->d_lexit,
+                                  pl->d_ltile_entry, pl->d_ltotals, pl->d_runs, pl->d_otile_first, pl->d_page_dyn, pl->d_status, 1));
+        HIP_TRY(ctx, launch_levels_expand(st, 1, src, pl->d_lregions, pl->d_lotile_prefix, n_lreg, pl->n_lotiles, pl->d_runs,
+                                          pl->d_otile_first, pl->d_ltotals, pl->d_page_dyn));
+    }
+    HIP_TRY(ctx, launch_page_scan(st, pl->d_chunks, n_chunks, pl->d_pages, n_pages, pl->d_page_dyn, pl->d_chunk_dyn, pl->d_status));
+    HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, (u32)pl->bool_pages.size(), pl->n_btiles,
+                              pl->d_chunks, pl->d_page_dyn));
+    if (n_sreg) {
+        HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->d_sregions, pl->d_stile_chain_prefix, n_sreg, pl->n_stiles_chain,
+                                  pl->d_sexit, pl->d_stile_entry, pl->d_stotals, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 0));
+        HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->d_sregions, pl->d_stile_chain_prefix, n_sreg, pl->n_stiles_chain,
+                                  pl->d_sexit, pl->d_stile_entry, pl->d_stotals, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 1));
+        HIP_TRY(ctx, launch_str_gather(st, src, pl->d_pages, pl->d_str_pages, pl->d_stile_prefix, (u32)pl->str_pages.size(),
+                                       pl->n_stiles, pl->d_chunks, pl->d_page_dyn, pl->d_sregions, n_sreg, pl->d_stotals, pl->d_status));
+    }
+    HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
+                             pl->d_row_tiles, pl->d_chunk_dyn));
+    HIP_TRY(ctx, hipEventRecord(pl->ev1, st));
+    pl->ran = true;
+    return PQD_OK;
+}
+
+int pqd_plan_sync(pqd_plan* pl) {
+    if (!pl || !pl->ran) return PQD_E_ARG;
+    pqd_ctx* ctx = pl->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!pl->h_chunk_dyn.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(pl->h_chunk_dyn.data(), pl->d_chunk_dyn, pl->h_chunk_dyn.size() * sizeof(ChunkDyn),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(pl->h_status, pl->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    pl->synced = true;
+    pl->last_status = map_status(pl->h_status[0]);
+    if (pl->last_status) {
+        char b[128];
+        snprintf(b, sizeof b, "decode failed: device status %d at item %d", pl->h_status[0], pl->h_status[1]);
+        ctx->err = b;
+    }
+    return pl->last_status;
+}
+
+int pqd_plan_last_ms(pqd_plan* pl, float* total_ms, float* plain_copy_ms) {
+    if (!pl || !pl->synced) return PQD_E_ARG;
+    if (total_ms) HIP_TRY(pl->ctx, hipEventElapsedTime(total_ms, pl->ev0, pl->ev1));
+    if (plain_copy_ms) HIP_TRY(pl->ctx, hipEventElapsedTime(plain_copy_ms, pl->evc0, pl->evc1));
+    return PQD_OK;
+}
+
+int pqd_plan_chunk_info(pqd_plan* pl, size_t c, pqd_chunk_info* info) {
+    if (!pl || !info || c >= pl->chunks.size() || !pl->synced) return PQD_E_ARG;
+    const ChunkRec& C = pl->chunks[c];
+    const ChunkDyn& D = pl->h_chunk_dyn[c];
+    info->n_levels = C.max_def > 0 ? (int64_t)C.n_levels : 0;
+    info->n_values = (int64_t)D.n_values;
+    info->value_bytes = C.width_bytes ? (int64_t)D.n_values * C.width_bytes : (C.phys_type == PQD_BOOLEAN ? (int64_t)D.n_values : 0);
+    info->chars_bytes = C.phys_type == PQD_BYTE_ARRAY ? (int64_t)D.chars : 0;
+    info->n_rows = C.max_def > 0 ? (int64_t)D.n_rows : (int64_t)D.n_values;
+    info->n_pages = C.n_pages;
+    return PQD_OK;
+}
+
+int pqd_plan_bytes(pqd_plan* pl, int64_t* bytes_in, int64_t* bytes_out, int64_t* plain_copy_bytes) {
+    if (!pl) return PQD_E_ARG;
+    if (bytes_in) *bytes_in = pl->bytes_in;
+    if (plain_copy_bytes) *plain_copy_bytes = pl->copy_bytes;
+    if (bytes_out) {
+        if (!pl->synced) return PQD_E_ARG;
+        int64_t o = 0;
+        for (size_t c = 0; c < pl->chunks.size(); c++) {
+            const ChunkRec& C = pl->chunks[c];
+            const ChunkDyn& D = pl->h_chunk_dyn[c];
+            if (C.max_def > 0) o += (int64_t)C.n_levels;
+            if (C.max_rep > 0) o += (int64_t)C.n_levels;
+            if (C.width_bytes) o += (int64_t)D.n_values * C.width_bytes;
+            else if (C.phys_type == PQD_BOOLEAN) o += (int64_t)D.n_values;
+            else o += (int64_t)D.chars + 4 * ((int64_t)D.n_values + 1);
+        }
+        *bytes_out = o;
+    }
+    return PQD_OK;
+}
+
+const void* pqd_plan_device_ptr(pqd_plan* pl, size_t c, pqd_output which) {
+    if (!pl || c >= pl->chunks.size() || (int)which < 0 || (int)which > 8) return nullptr;
+    return pl->outs[c].p[which];
+}
+
+int64_t pqd_plan_fetch(pqd_plan* pl, size_t c, pqd_output which, void* dst, size_t cap) {
+    if (!pl || c >= pl->chunks.size() || (int)which < 0 || (int)which > 8 || !pl->synced) return PQD_E_ARG;
+    pqd_ctx* ctx = pl->ctx;
+    const u8* p = pl->outs[c].p[which];
+    if (!p) return 0;
+    pqd_chunk_info ci;
+    pqd_plan_chunk_info(pl, c, &ci);
+    size_t n = 0;
+    switch (which) {
+    case PQD_OUT_DEFS: n = (size_t)ci.n_levels; break;
+    case PQD_OUT_REPS: n = (size_t)ci.n_levels; break;
+    case PQD_OUT_VALUES: n = (size_t)ci.value_bytes; break;
+    case PQD_OUT_OFFSETS: n = ((size_t)ci.n_values + 1) * 4; break;
+    case PQD_OUT_CHARS: n = (size_t)ci.chars_bytes; break;
+    case PQD_OUT_VALIDITY: n = ((size_t)ci.n_levels + 7) / 8; break;
+    case PQD_OUT_PAGE_NONNULL: n = (size_t)ci.n_pages * 8; break;
+    case PQD_OUT_ROW_LEVEL_OFF: case PQD_OUT_ROW_VALUE_OFF: n = ((size_t)ci.n_rows + 1) * 8; break;
+    }
+    if (n > pl->outs[c].cap[which]) n = pl->outs[c].cap[which];
+    if (n > cap) return fail(ctx, PQD_E_ARG, "destination too small");
+    if (n == 0) return 0;
+    if (!dst) return PQD_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, p, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return (int64_t)n;
+}
+
+int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks, const pqd_page_desc* pages, size_t n_pages,
+               const void* src_host, size_t src_len, pqd_plan** out) {
+    if (!ctx || !out || !src_host) return PQD_E_ARG;
+    pqd_plan* pl = nullptr;
+    int rc = pqd_plan_create(ctx, chunks, n_chunks, pages, n_pages, src_host, src_len, &pl);
+    if (rc) return rc;
+    pl->owned_src = (u8*)pqd_device_alloc(ctx, src_len);
+    if (!pl->owned_src) { pqd_plan_destroy(pl); return fail(ctx, PQD_E_NOMEM, "device allocation for the source failed"); }
+    if ((rc = pqd_copy_to_device(ctx, pl->owned_src, src_host, src_len)) || (rc = pqd_plan_run(pl, pl->owned_src))) {
+        pqd_plan_destroy(pl);
+        return rc;
+    }
+    rc = pqd_plan_sync(pl);
+    *out = pl;  // kept even on a decode error so the caller can inspect partial results
+    return rc;
+}
+
+int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block_, size_t block_len, int esz, void* out_host,
+                   size_t max_values, int64_t* n_decoded) {
+    if (!ctx || !block_ || !n_decoded || width < 0 || width > 32) return PQD_E_ARG;
+    if (!(esz == 1 || esz == 2 || esz == 4) || width > 8 * esz) return fail(ctx, PQD_E_ARG, "element size too small for width");
+    if (max_values > 0x7fffffffu) return fail(ctx, PQD_E_ARG, "max_values too large");
+    const u8* block = (const u8*)block_;
+    if (block_len < 4) return fail(ctx, PQD_E_CORRUPT, "level block shorter than its length field");
+    int32_t len;
+    memcpy(&len, block, 4);
+    if (len < 0 || (size_t)len > block_len - 4) return fail(ctx, PQD_E_CORRUPT, "level block length outside the buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const u32 n_tiles = ((u32)len + CH_T - 1) / CH_T;
+    const u32 n_otiles = (u32)((max_values + OT - 1) / OT);
+    ArenaPlan ap;
+    const size_t o_src = ap.take((size_t)len + 64);
+    const size_t o_reg = ap.take(sizeof(Region));
+    const size_t o_tp = ap.take(8), o_otp = ap.take(8);
+    const size_t o_exit = ap.take((size_t)n_tiles * CH_E_LEVELS * sizeof(ExitRec));
+    const size_t o_tot = ap.take(sizeof(RegionTotal));
+    const size_t o_runs = ap.take((size_t)len * sizeof(RunRec));
+    const size_t o_out = ap.take(max_values * (size_t)esz + 64);
+    const size_t o_ff = ap.total;
+    const size_t o_te = ap.take((size_t)n_tiles * sizeof(TileEntry));
+    const size_t o_otf = ap.take((size_t)n_otiles * 4);
+    const size_t ff_end = ap.total;
+    const size_t o_zero = ap.total;
+    const size_t o_pdyn = ap.take(sizeof(PageDyn));
+    const size_t o_status = ap.take(16);
+    u8* A = nullptr;
+    hipError_t e = hipMalloc((void**)&A, ap.total);
+    if (e != hipSuccess) return fail(ctx, PQD_E_NOMEM, "hipMalloc failed", e);
+    struct Free { u8* p; ~Free() { (void)hipFree(p); } } fr{A};
+    Region R;
+    memset(&R, 0, sizeof R);
+    R.src_off = 0; R.len = (u32)len; R.width = (u32)width; R.n_out = 0; R.out = A + o_out; R.count_level = ERR_POS;
+    const u32 tp[2] = {0, n_tiles}, otp[2] = {0, n_otiles};
+    HIP_TRY(ctx, hipMemsetAsync(A + o_ff, 0xFF, ff_end - o_ff, st));
+    HIP_TRY(ctx, hipMemsetAsync(A + o_zero, 0, ap.total - o_zero, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_src, block + 4, (size_t)len, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_reg, &R, sizeof R, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_tp, tp, 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_otp, otp, 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, A + o_src, (Region*)(A + o_reg), (u32*)(A + o_tp), 1, n_tiles, (ExitRec*)(A + o_exit),
+                              (TileEntry*)(A + o_te), (RegionTotal*)(A + o_tot), (RunRec*)(A + o_runs), (u32*)(A + o_otf),
+                              (PageDyn*)(A + o_pdyn), (int*)(A + o_status), 0));
+    RegionTotal tot;
+    int status[4];
+    HIP_TRY(ctx, hipMemcpyAsync(&tot, A + o_tot, sizeof tot, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(status, A + o_status, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (status[0] || tot.err) return fail(ctx, PQD_E_CORRUPT, "malformed level block");
+    *n_decoded = (int64_t)tot.vals;
+    const u64 n_emit = tot.vals < max_values ? tot.vals : max_values;
+    if (n_emit == 0) return PQD_OK;
+    if (!out_host) return PQD_E_ARG;
+    R.n_out = n_emit;
+    const u32 otp2[2] = {0, (u32)((n_emit + OT - 1) / OT)};
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_reg, &R, sizeof R, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_otp, otp2, 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, A + o_src, (Region*)(A + o_reg), (u32*)(A + o_tp), 1, n_tiles, (ExitRec*)(A + o_exit),
+                              (TileEntry*)(A + o_te), (RegionTotal*)(A + o_tot), (RunRec*)(A + o_runs), (u32*)(A + o_otf),
+                              (PageDyn*)(A + o_pdyn), (int*)(A + o_status), 1));
+    HIP_TRY(ctx, launch_levels_expand(st, esz, A + o_src, (Region*)(A + o_reg), (u32*)(A + o_otp), 1, otp2[1], (RunRec*)(A + o_runs),
+                                      (u32*)(A + o_otf), (RegionTotal*)(A + o_tot), (PageDyn*)(A + o_pdyn)));
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, A + o_out, n_emit * (size_t)esz, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return PQD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+// Tables shared between the host planner (pqd_api.cpp) and the kernels (pqd_kernels.hip).
+// All of them live in HBM; the host builds the static ones once per plan.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pqd {
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr u32 ERR_POS = 0xFFFFFFFFu;
+
+// device status codes (mapped to pqd_status by the host)
+constexpr int ST_CORRUPT = 1, ST_NONCANONICAL = 2, ST_UNSUPPORTED = 3;
+
+// parquet physical types
+constexpr int PT_BOOLEAN = 0, PT_BYTE_ARRAY = 6;
+
+// ---- PLAIN value gather -------------------------------------------------------------------
+constexpr int CP_THREADS = 256;
+constexpr int CP_UNROLL = 4;
+constexpr u32 CP_BLK = CP_THREADS * 16 * CP_UNROLL;  // bytes per block iteration (16 KiB)
+
+struct Seg {
+    u64 src_off;  // byte offset in the source buffer
+    u8* dst;      // destination address
+    u64 len;
+};
+
+// ---- chain resolution (run headers, BYTE_ARRAY lengths) ---------------------------------------
+constexpr int KIND_LEVELS = 0, KIND_STRINGS = 1;
+constexpr u32 CH_T = 2048;        // source bytes per tile
+constexpr u32 CH_THREADS = 256;
+constexpr u32 CH_PPT = CH_T / CH_THREADS;
+constexpr u32 CH_HALO = 16;
+constexpr u32 CH_E_LEVELS = 512;  // tabulated entry positions per tile: covers a 64-group run at width <= 7
+constexpr u32 CH_E_STRINGS = 64;  // covers values up to 60 bytes; longer ones take the serial hop
+
+constexpr u32 OT = 4096;          // level values per expand tile
+constexpr u32 EX_CAP = 2048;      // runs staged in LDS per expand batch
+constexpr u32 BT = 4096;          // bools per tile
+constexpr u32 ST = 4096;          // string chars per gather tile
+constexpr u32 RT = 4096;          // levels per row-offset tile
+
+struct Region {
+    u64 src_off;     // start of the chain bytes (after the 4-byte length for level blocks)
+    u32 len;         // chain bytes
+    u32 width;       // level bit width
+    u32 tile_base;   // first tile of the region in the global tile numbering
+    u32 otile_base;  // first expand tile (levels)
+    u64 run_base;    // first entry of the region in the run table (levels)
+    u64 n_out;       // levels: values to emit (page num_values); strings: upper bound of values in the page
+    u8* out;         // levels: destination of value 0; strings: the chunk's offsets array
+    u32 page;        // page index
+    u32 count_level; // levels: count values equal to this into page_dyn[page].nn; ERR_POS = do not count
+};
+
+struct ExitRec { u32 tgt; u32 cnt; u64 vals; };
+struct TileEntry { u32 pos; u32 cnt; u64 vals; };
+struct RegionTotal { u32 cnt; u32 err; u64 vals; };
+struct RunRec { u32 out_off; u32 info; };
+
+// ---- pages and chunks ----------------------------------------------------------------------
+struct PageRec {
+    u64 val_src_off;  // source offset of the values region (payload after the level blocks)
+    u32 val_len;      // bytes in the values region
+    u32 num_values;   // DataPageHeader.num_values (levels, nulls included)
+    u32 chunk;
+    u32 pad;
+};
+struct PageDyn {
+    u32 nn;        // non-null values of the page (def == max_def)
+    u32 pad;
+    u64 val_off;   // dense value index of the page's first value within its chunk
+    u64 char_off;  // strings: char index of the page's first byte within its chunk
+};
+struct ChunkRec {
+    int phys_type, max_def, max_rep;
+    u32 width_bytes;  // 4 / 8 for fixed-width types, else 0
+    u32 first_page, n_pages;
+    u64 n_levels;
+    u64 stream_len;   // sum of the pages' values-region lengths
+    u64 req_values;   // required chunk: parquet.Page.N, the number of values the typed Read takes
+    u8 *defs, *reps, *values, *offsets, *chars, *validity, *page_nonnull, *row_level_off, *row_value_off;
+};
+struct ChunkDyn {
+    u64 n_values, chars, n_rows;
+};
+struct RowTile { u32 rows, vals; u64 row_base, val_base; };
+
+// ---- launchers -----------------------------------------------------------------------------
+hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32* blk_prefix, u32 n_segs, u32 n_blocks,
+                       u32 max_grid);
+hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const Region* regions, const u32* tile_prefix,
+                        u32 n_regions, u32 n_tiles, ExitRec* exit_tbl, TileEntry* tile_entry, RegionTotal* totals,
+                        RunRec* run_tbl, u32* otile_first_run, const PageDyn* page_dyn, int* status, int phase);
+hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_prefix,
+                                u32 n_regions, u32 n_otiles, const RunRec* run_tbl, const u32* otile_first_run,
+                                const RegionTotal* totals, PageDyn* page_dyn);
+hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks, const PageRec* pages, u32 n_pages,
+                            PageDyn* page_dyn, ChunkDyn* chunk_dyn, int* status);
+hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids, const u32* btile_prefix,
+                        u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn);
+hipError_t launch_str_gather(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids,
+                             const u32* stile_prefix, u32 n_spages, u32 n_stiles, const ChunkRec* chunks,
+                             const PageDyn* page_dyn, const Region* regions, u32 n_regions, const RegionTotal* totals,
+                             int* status);
+hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_prefix, const u32* chunk_ids, u32 n_rchunks,
+                       u32 n_rtiles, RowTile* tiles, ChunkDyn* chunk_dyn);
+
+}  // namespace pqd

@@ -1,0 +1,897 @@
+// HIP kernels for gfx950 (MI355X): Parquet DATA_PAGE v1 decode — hybrid RLE/bit-packed levels and
+// PLAIN values.  Everything here is byte/integer movement bounded by HBM bandwidth; there is no
+// contraction anywhere, so no MFMA.  Wavefront = 64 lanes; workgroups are 256 threads.
+//
+// Reference behaviour each kernel reproduces (paths inside parsyl/parquet):
+//   k_copy            binary.Read of PLAIN little-endian values + page concatenation
+//                     (cmd/parquetgen/gen/template_required.go:31-33, template_optional.go:48-50,
+//                      fields.go:131,313)
+//   k_chain<LEVELS>   run-header walk of rle.Read (internal/rle/rle.go:175-193, readLEB128 :274-290)
+//   k_levels_expand   readRLE :218-230, readRLEBitPacked :197-216, bitpack.Unpack
+//                     (internal/bitpack/bitpack.go:76-141), truncation to NumValues (fields.go:300,308),
+//                     valsFromDefs (fields.go:220-228)
+//   k_bools           GetBools / unpackBools (parquet.go:455-505)
+//   k_chain<STRINGS>, k_str_gather
+//                     the [int32 length][bytes] walk of template_string.go:47-58 /
+//                     template_string_optional.go:68-79
+//   k_rows_*          per-row level consumption of the generated write functions
+//                     (cmd/parquetgen/dremel/write_repeated.go:62-80, write_optional.go:22-31)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pqd_device.h"
+
+namespace pqd {
+
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
+typedef u64 u64_u __attribute__((aligned(1)));
+typedef u32 u32_u __attribute__((aligned(1)));
+
+static __device__ __forceinline__ void set_status(int* status, int code, u32 where) {
+    if (atomicCAS(status, 0, code) == 0) status[1] = (int)where;
+}
+
+// Largest i in [0, n) with prefix[i] <= x; prefix has n + 1 non-decreasing entries, prefix[0] == 0.
+static __device__ __forceinline__ u32 find_owner(const u32* __restrict__ prefix, u32 n, u32 x) {
+    u32 lo = 0, hi = n;
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (prefix[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// =====================================================================================
+// k_copy — gathers byte segments (the values regions of pages) into dense output arrays.
+// One block moves CP_BLK bytes of one segment.  Stores are 16-byte aligned dwordx4; loads are
+// dwordx4 at whatever alignment the page payload has in the file (gfx950 global loads need no
+// alignment).  Each wave instruction covers 1 KiB of contiguous memory on both sides.
+// =====================================================================================
+__global__ __launch_bounds__(CP_THREADS) void k_copy(const u8* __restrict__ src_base, const Seg* __restrict__ segs,
+                                                     const u32* __restrict__ blk_prefix, u32 n_segs, u32 n_blocks) {
+    const u32 tid = threadIdx.x;
+    for (u32 b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const u32 s = find_owner(blk_prefix, n_segs, b);
+        const Seg sg = segs[s];
+        const u32 bi = b - blk_prefix[s];
+        const u64 a = (u64)sg.dst & 15;            // destination misalignment
+        // v-space: v = offset in segment + a, so that v % 16 == 0 ⇔ destination 16-byte aligned
+        const u8* sv = src_base + sg.src_off - a;
+        u8* dv = sg.dst - a;
+        const u64 v_end = a + sg.len;
+        u64 v_lo = (u64)bi * CP_BLK;
+        u64 v_hi = v_lo + CP_BLK < v_end ? v_lo + CP_BLK : v_end;
+        if (v_lo < a) v_lo = a;
+        const u64 u0 = (v_lo + 15) & ~15ull;
+        const u64 u1 = v_hi & ~15ull;
+        if (u1 > u0) {
+            const u32 n_units = (u32)((u1 - u0) >> 4);
+            u32x4 r[CP_UNROLL];
+#pragma unroll
+            for (int i = 0; i < CP_UNROLL; i++) {
+                const u32 k = tid + i * CP_THREADS;
+                if (k < n_units) r[i] = __builtin_nontemporal_load((const u32x4_u*)(sv + u0 + (u64)k * 16));
+            }
+#pragma unroll
+            for (int i = 0; i < CP_UNROLL; i++) {
+                const u32 k = tid + i * CP_THREADS;
+                if (k < n_units) __builtin_nontemporal_store(r[i], (u32x4*)(dv + u0 + (u64)k * 16));
+            }
+            // head [v_lo, u0) and tail [u1, v_hi): fewer than 16 bytes each
+            if (tid < (u32)(u0 - v_lo)) dv[v_lo + tid] = sv[v_lo + tid];
+            if (tid < (u32)(v_hi - u1)) dv[u1 + tid] = sv[u1 + tid];
+        } else {
+            // fewer than 31 bytes in total
+            if (tid < (u32)(v_hi - v_lo)) dv[v_lo + tid] = sv[v_lo + tid];
+        }
+    }
+}
+
+// =====================================================================================
+// Chain resolution.  Both run headers of a hybrid-RLE block and PLAIN BYTE_ARRAY values form a
+// chain: the position of element k+1 is only known after decoding element k.  Three kernels turn
+// the chain into parallel work:
+//   k_chain<.., false>   per CH_T-byte tile: treat EVERY byte as a possible element start, compute its
+//                        successor, then pointer-double inside LDS until every start knows where its
+//                        chain leaves the tile (and how many elements / level values it passes).
+//                        The first E starts of each tile are written to an exit table.
+//   k_chain_resolve      one thread per region hops tile to tile through the exit table and records
+//                        where the true chain enters each tile.
+//   k_chain<.., true>    per tile again, now marking the true chain while doubling
+//                        (marked ∪ jump_2^k(marked) doubles the marked prefix each round), then emits
+//                        one record per true element.
+// =====================================================================================
+
+struct GlobalBytes {
+    const u8* p;
+    __device__ __forceinline__ u32 operator()(u32 q) const { return p[q]; }
+};
+struct LdsBytes {
+    const u8* p;  // LDS copy of the tile
+    u32 base;     // region position of p[0]
+    __device__ __forceinline__ u32 operator()(u32 q) const { return p[q - base]; }
+};
+
+// One hybrid-RLE run header at region position p (p < L).  nxt = position of the next header
+// (== L when the block ends), ERR_POS when the reference would fail:
+//   header even → RLE run: count = header >> 1, value in ceil(w/8) bytes (rle.go:218-244)
+//   header odd  → bit-packed: groups = header >> 1, values = 8*groups, w*groups bytes; a short read is
+//                 zero padded, a read at the very end of the block is io.EOF (rle.go:197-216)
+// info = (position of the value byte(s) or of the packed bytes) << 1 | bit-packed flag.
+template <class Bytes>
+static __device__ __forceinline__ void rle_step(const Bytes& B, u32 p, u32 L, u32 w, u32& nxt, u64& vals, u32& info) {
+    u64 h = 0;
+    u32 q = p, shift = 0;
+    bool ok = false;
+    for (int k = 0; k < 10; k++) {
+        if (q >= L) break;
+        const u32 b = B(q++);
+        h |= (u64)(b & 0x7F) << shift;
+        shift += 7;
+        if (!(b & 0x80)) { ok = true; break; }
+    }
+    nxt = ERR_POS; vals = 0; info = 0;
+    if (!ok) return;
+    if ((h & 1) == 0) {
+        const u64 count = h >> 1;
+        if (count > (1ull << 31)) return;
+        const u32 bw = (w + 7) >> 3;
+        if (bw > L - q) return;       // io.EOF reading the run value
+        info = q << 1;
+        nxt = q + bw;
+        vals = count;
+    } else {
+        const u64 groups = h >> 1;
+        if (groups > (1ull << 28)) return;
+        vals = groups * 8;
+        info = (q << 1) | 1;
+        if (w == 0) { nxt = q; return; }
+        if (q >= L) { vals = 0; return; }  // exhausted reader: io.EOF
+        const u64 e = (u64)q + (u64)w * groups;
+        nxt = e > L ? L : (u32)e;
+    }
+}
+
+// One PLAIN BYTE_ARRAY value at region position p: int32 LE length, then the bytes
+// (template_string.go:47-58).  A negative length panics in the reference; a value running past the
+// region is reported as corrupt.
+template <class Bytes>
+static __device__ __forceinline__ void str_step(const Bytes& B, u32 p, u32 L, u32& nxt) {
+    nxt = ERR_POS;
+    if (L - p < 4) return;
+    const u32 len = B(p) | (B(p + 1) << 8) | (B(p + 2) << 16) | (B(p + 3) << 24);
+    if (len & 0x80000000u) return;
+    const u64 e = (u64)p + 4 + len;
+    if (e > L) return;
+    nxt = (u32)e;
+}
+
+template <int KIND, bool MARK>
+__global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                                                      const u32* __restrict__ tile_prefix, u32 n_regions,
+                                                      ExitRec* __restrict__ exit_tbl, const TileEntry* __restrict__ tile_entry,
+                                                      RunRec* __restrict__ run_tbl, u32* __restrict__ otile_first_run,
+                                                      const PageDyn* __restrict__ page_dyn) {
+    constexpr u32 E = KIND == KIND_LEVELS ? CH_E_LEVELS : CH_E_STRINGS;
+    __shared__ u32 s_tgt[2][CH_T];
+    __shared__ unsigned short s_cnt[2][CH_T];
+    __shared__ u64 s_acc[KIND == KIND_LEVELS ? 2 : 1][KIND == KIND_LEVELS ? CH_T : 1];
+    __shared__ __attribute__((aligned(16))) u8 s_b[CH_T + CH_HALO];
+    __shared__ u8 s_mark[MARK ? CH_T : 1];
+
+    const u32 tid = threadIdx.x;
+    const u32 tile = blockIdx.x;
+    const u32 ri = find_owner(tile_prefix, n_regions, tile);
+    const Region R = regions[ri];
+    const u32 L = R.len;
+    const u32 tb = (tile - tile_prefix[ri]) * CH_T;  // region position of the tile start
+    const u32 te = tb + CH_T;
+    const u8* rsrc = src_base + R.src_off;
+
+    TileEntry ent;
+    if (MARK) {
+        ent = tile_entry[tile];
+        if (ent.pos == ERR_POS) return;  // the true chain never starts an element in this tile
+    }
+
+    // stage the tile (+ halo for headers that straddle the tile end) in LDS; bytes past L read as 0
+    for (u32 i = tid * 8; i < CH_T + CH_HALO; i += CH_THREADS * 8) {
+        const u32 p = tb + i;
+        u64 v = 0;
+        if (p < L) {
+            if (L - p >= 8) v = *(const u64_u*)(rsrc + p);
+            else for (u32 k = 0; k < L - p; k++) v |= (u64)rsrc[p + k] << (8 * k);
+        }
+        *(u64*)(s_b + i) = v;
+    }
+    if (MARK) for (u32 i = tid; i < CH_T; i += CH_THREADS) s_mark[i] = 0;
+    __syncthreads();
+
+    const LdsBytes B{s_b, tb};
+    for (u32 k = 0; k < CH_PPT; k++) {
+        const u32 i = tid + k * CH_THREADS;
+        const u32 p = tb + i;
+        u32 nxt = p;
+        u64 vals = 0;
+        unsigned short c = 0;
+        if (p < L) {
+            c = 1;
+            if (KIND == KIND_LEVELS) { u32 info; rle_step(B, p, L, R.width, nxt, vals, info); }
+            else str_step(B, p, L, nxt);
+        }
+        s_tgt[0][i] = nxt;
+        s_cnt[0][i] = c;
+        if (KIND == KIND_LEVELS) s_acc[0][i] = vals;
+    }
+    if (MARK && tid == 0) s_mark[ent.pos - tb] = 1;
+    __syncthreads();
+
+    int cur = 0;
+    for (int round = 0; round < 12; round++) {
+        int changed = 0;
+        for (u32 k = 0; k < CH_PPT; k++) {
+            const u32 i = tid + k * CH_THREADS;
+            u32 t = s_tgt[cur][i];
+            unsigned short c = s_cnt[cur][i];
+            u64 a = 0;
+            if (KIND == KIND_LEVELS) a = s_acc[cur][i];
+            if (t < te && t < L && tb + i < L) {
+                const u32 j = t - tb;
+                if (MARK && s_mark[i]) s_mark[j] = 1;
+                t = s_tgt[cur][j];
+                c = (unsigned short)(c + s_cnt[cur][j]);
+                if (KIND == KIND_LEVELS) a += s_acc[cur][j];
+                changed = 1;
+            }
+            s_tgt[cur ^ 1][i] = t;
+            s_cnt[cur ^ 1][i] = c;
+            if (KIND == KIND_LEVELS) s_acc[cur ^ 1][i] = a;
+        }
+        cur ^= 1;
+        if (!__syncthreads_or(changed)) break;
+    }
+
+    if (!MARK) {
+        // exit table: where the chain started at each of the first E positions leaves the tile
+        for (u32 i = tid; i < E; i += CH_THREADS) {
+            ExitRec x;
+            x.tgt = s_tgt[cur][i];
+            x.cnt = s_cnt[cur][i];
+            x.vals = KIND == KIND_LEVELS ? s_acc[cur][i] : 0;
+            exit_tbl[(u64)tile * E + i] = x;
+        }
+        return;
+    }
+
+    // ---- MARK: one record per element of the true chain that starts in this tile
+    const u32 e_i = ent.pos - tb;
+    const u32 K = s_cnt[cur][e_i];
+    for (u32 k = 0; k < CH_PPT; k++) {
+        const u32 i = tid + k * CH_THREADS;
+        if (!s_mark[i]) continue;
+        const u32 p = tb + i;
+        const u32 rank = ent.cnt + (K - s_cnt[cur][i]);  // index of this element within the region
+        if (KIND == KIND_LEVELS) {
+            u32 nxt, info;
+            u64 vals;
+            rle_step(B, p, L, R.width, nxt, vals, info);
+            const u64 o = ent.vals + (s_acc[cur][e_i] - s_acc[cur][i]);  // first level value of the run
+            const u64 n_out = R.n_out;
+            RunRec rr;
+            rr.out_off = o < n_out ? (u32)o : (u32)n_out;
+            rr.info = info;
+            run_tbl[R.run_base + rank] = rr;
+            // which output tiles start inside this run
+            if (vals > 0 && o < n_out) {
+                u64 oe = o + vals < n_out ? o + vals : n_out;
+                for (u64 t = (o + OT - 1) / OT; t * OT < oe; t++) otile_first_run[R.otile_base + t] = rank;
+            }
+        } else {
+            // string `rank` of the page starts at p: its chars begin at p + 4; every earlier string
+            // of the page contributed 4 length bytes
+            if (rank < R.n_out) {  // a page can never hold more values than levels
+                const PageDyn pd = page_dyn[R.page];
+                int32_t* offsets = (int32_t*)R.out;
+                offsets[pd.val_off + rank] = (int32_t)(pd.char_off + (u64)p - 4ull * rank);
+            }
+        }
+    }
+}
+
+// One thread per region: hop from tile to tile along the true chain.
+template <int KIND>
+__global__ void k_chain_resolve(const u8* __restrict__ src_base, const Region* __restrict__ regions, u32 n_regions,
+                                const ExitRec* __restrict__ exit_tbl, TileEntry* __restrict__ tile_entry,
+                                RegionTotal* __restrict__ totals, int* __restrict__ status) {
+    constexpr u32 E = KIND == KIND_LEVELS ? CH_E_LEVELS : CH_E_STRINGS;
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_regions) return;
+    const Region R = regions[r];
+    const u32 L = R.len;
+    const GlobalBytes B{src_base + R.src_off};
+    u32 p = 0, cnt = 0;
+    u64 vals = 0;
+    bool err = false;
+    while (p < L) {
+        const u32 t = p / CH_T, off = p % CH_T;
+        TileEntry te;
+        te.pos = p; te.cnt = cnt; te.vals = vals;
+        tile_entry[R.tile_base + t] = te;
+        u32 tgt;
+        if (off < E) {
+            const ExitRec x = exit_tbl[(u64)(R.tile_base + t) * E + off];
+            tgt = x.tgt; cnt += x.cnt; vals += x.vals;
+        } else {
+            // entry beyond the tabulated window: walk this tile element by element
+            const u32 tend = (t + 1) * CH_T < L ? (t + 1) * CH_T : L;
+            u32 q = p;
+            while (q < tend) {
+                u32 nxt; u64 v = 0;
+                if (KIND == KIND_LEVELS) { u32 info; rle_step(B, q, L, R.width, nxt, v, info); }
+                else str_step(B, q, L, nxt);
+                cnt++; vals += v;
+                q = nxt;
+                if (nxt == ERR_POS) break;
+            }
+            tgt = q;
+        }
+        if (tgt == ERR_POS) { err = true; break; }
+        p = tgt;
+    }
+    RegionTotal tot;
+    tot.cnt = cnt; tot.err = err ? 1 : 0; tot.vals = vals;
+    totals[r] = tot;
+    if (err) set_status(status, ST_CORRUPT, r);
+    else if (KIND == KIND_LEVELS && vals < R.n_out) set_status(status, ST_CORRUPT, r);  // defs[:NumValues] out of range
+}
+
+// =====================================================================================
+// k_levels_expand — one block per OT level values of one page: expands the runs that overlap the
+// tile into the dense level array (u8; u16/u32 for the standalone wide decode) and counts
+// def == max_def for the page (valsFromDefs).
+// =====================================================================================
+static __device__ __forceinline__ u64 load_u64_guarded(const u8* p, u32 pos, u32 L) {
+    if (pos < L && L - pos >= 8) return *(const u64_u*)(p + pos);
+    u64 v = 0;
+    for (u32 k = 0; k < 8; k++) if (pos + k < L) v |= (u64)p[pos + k] << (8 * k);
+    return v;
+}
+
+template <int ESZ>
+__global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                                                       const u32* __restrict__ otile_prefix, u32 n_regions,
+                                                       const RunRec* __restrict__ run_tbl, const u32* __restrict__ otile_first_run,
+                                                       const RegionTotal* __restrict__ totals, PageDyn* __restrict__ page_dyn) {
+    __shared__ u32 s_out[EX_CAP + 1];
+    __shared__ u32 s_info[EX_CAP];
+    __shared__ u32 s_ctl[2];
+    const u32 tid = threadIdx.x;
+    const u32 ot = blockIdx.x;
+    const u32 ri = find_owner(otile_prefix, n_regions, ot);
+    const Region R = regions[ri];
+    const u32 L = R.len, w = R.width;
+    const u8* rsrc = src_base + R.src_off;
+    const u32 n_out = (u32)R.n_out;
+    const u32 t_lo = (ot - otile_prefix[ri]) * OT;
+    const u32 t_hi = t_lo + OT < n_out ? t_lo + OT : n_out;
+    const u32 n_runs = totals[ri].cnt;
+    u32 first = otile_first_run[ot];
+    if (first == ERR_POS || totals[ri].err) return;  // short or corrupt block: status already set
+    const RunRec* runs = run_tbl + R.run_base;
+
+    // this thread's 16 (ESZ == 1) or 16/ESZ... values: always 16 values per thread
+    const u32 o0 = t_lo + tid * 16;
+    u64 acc_lo = 0, acc_hi = 0;           // ESZ == 1: 16 result bytes
+    u32 wide[ESZ == 1 ? 1 : 16];          // ESZ > 1: results (static indexing only)
+    u32 cur = t_lo;                        // everything below `cur` is done
+    while (cur < t_hi) {
+        // stage up to EX_CAP runs starting at `first`
+        __syncthreads();
+        const u32 m = n_runs - first < EX_CAP ? n_runs - first : EX_CAP;
+        if (m == 0) break;
+        for (u32 i = tid; i < m; i += 256) {
+            const RunRec rr = runs[first + i];
+            s_out[i] = rr.out_off;
+            s_info[i] = rr.info;
+        }
+        if (tid == 0) {
+            // end of the range the staged runs cover
+            s_out[m] = first + m < n_runs ? runs[first + m].out_off : n_out;
+        }
+        __syncthreads();
+        const u32 batch_hi = s_out[m] < t_hi ? s_out[m] : t_hi;
+        // my values inside [max(cur,o0), min(batch_hi, o0+16))
+        u32 lo = o0 > cur ? o0 : cur;
+        u32 hi = o0 + 16 < batch_hi ? o0 + 16 : batch_hi;
+        if (lo < hi) {
+            // last staged run with out_off <= lo
+            u32 a = 0, b = m;
+            while (b - a > 1) { const u32 mid = (a + b) >> 1; if (s_out[mid] <= lo) a = mid; else b = mid; }
+            u32 j = a;
+            u32 oo = lo;
+            while (oo < hi) {
+                while (s_out[j + 1] <= oo) j++;
+                const u32 seg_hi = s_out[j + 1] < hi ? s_out[j + 1] : hi;
+                const u32 info = s_info[j];
+                const u32 pos = info >> 1;
+                if ((info & 1) == 0 || w == 0) {
+                    // RLE run: value in ceil(w/8) little-endian bytes
+                    u32 val = 0;
+                    const u32 bw = (w + 7) >> 3;
+                    for (u32 k = 0; k < bw; k++) val |= (u32)rsrc[pos + k] << (8 * k);
+                    if (ESZ == 1) {
+                        const u64 splat = (u64)(val & 0xFF) * 0x0101010101010101ull;
+                        for (u32 x = oo; x < seg_hi; x++) {
+                            const u32 kk = x - o0;
+                            if (kk < 8) acc_lo |= (splat & 0xFFull) << (8 * kk); else acc_hi |= (splat & 0xFFull) << (8 * (kk - 8));
+                        }
+                    } else {
+#pragma unroll
+                        for (int kk = 0; kk < 16; kk++) if (o0 + kk >= oo && o0 + kk < seg_hi) wide[kk] = val;
+                    }
+                } else {
+                    // bit-packed run: value idx sits at bit idx*w of the packed bytes (LSB first)
+                    const u32 idx0 = oo - s_out[j];
+                    if (ESZ == 1) {
+                        u32 x = oo;
+                        while (x < seg_hi) {
+                            const u32 n = seg_hi - x < 8 ? seg_hi - x : 8;
+                            const u64 bit = (u64)(idx0 + (x - oo)) * w;
+                            const u64 win = load_u64_guarded(rsrc, pos + (u32)(bit >> 3), L) >> (bit & 7);
+                            const u32 mask = (1u << w) - 1;
+                            for (u32 q = 0; q < n; q++) {
+                                const u64 v = (win >> (q * w)) & mask;
+                                const u32 kk = x + q - o0;
+                                if (kk < 8) acc_lo |= v << (8 * kk); else acc_hi |= v << (8 * (kk - 8));
+                            }
+                            x += n;
+                        }
+                    } else {
+#pragma unroll
+                        for (int kk = 0; kk < 16; kk++) {
+                            if (o0 + kk >= oo && o0 + kk < seg_hi) {
+                                const u64 bit = (u64)(idx0 + (o0 + kk - oo)) * w;
+                                const u64 win = load_u64_guarded(rsrc, pos + (u32)(bit >> 3), L) >> (bit & 7);
+                                wide[kk] = w == 32 ? (u32)win : (u32)(win & ((1ull << w) - 1));
+                            }
+                        }
+                    }
+                }
+                oo = seg_hi;
+            }
+        }
+        if (batch_hi >= t_hi) break;
+        // next batch: continue from the first run that reaches past batch_hi
+        if (tid == 0) {
+            u32 a = 0, b = m;  // last staged run with out_off <= batch_hi
+            while (b - a > 1) { const u32 mid = (a + b) >> 1; if (s_out[mid] <= batch_hi) a = mid; else b = mid; }
+            s_ctl[0] = s_out[m] <= batch_hi ? first + m : first + a;
+            s_ctl[1] = batch_hi;
+        }
+        __syncthreads();
+        const u32 nf = s_ctl[0];
+        if (nf == first && s_ctl[1] == cur) break;  // no progress (cannot happen for a consistent table)
+        first = nf;
+        cur = s_ctl[1];
+    }
+
+    // store + count
+    u32 n_mine = 0;
+    if (o0 < t_hi) n_mine = t_hi - o0 < 16 ? t_hi - o0 : 16;
+    if (ESZ == 1) {
+        u8* dst = R.out + o0;
+        if (n_mine == 16 && (((u64)dst) & 15) == 0) {
+            u32x4 v;
+            v.x = (u32)acc_lo; v.y = (u32)(acc_lo >> 32); v.z = (u32)acc_hi; v.w = (u32)(acc_hi >> 32);
+            *(u32x4*)dst = v;
+        } else {
+            for (u32 k = 0; k < n_mine; k++) dst[k] = (u8)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8)));
+        }
+        if (R.count_level != ERR_POS) {
+            const u64 cl = (u64)(R.count_level & 0xFF) * 0x0101010101010101ull;
+            u32 c = 0;
+            for (u32 k = 0; k < n_mine; k++) {
+                const u32 byte = (u32)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8))) & 0xFF;
+                c += byte == (u32)(cl & 0xFF);
+            }
+            // wave sum, then one atomic per wave
+            for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+            if ((tid & 63) == 0 && c) atomicAdd(&page_dyn[R.page].nn, c);
+        }
+    } else if (ESZ == 2) {
+        unsigned short* dst = (unsigned short*)R.out + o0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) if ((u32)k < n_mine) dst[k] = (unsigned short)wide[k];
+    } else {
+        u32* dst = (u32*)R.out + o0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) if ((u32)k < n_mine) dst[k] = wide[k];
+    }
+}
+
+// =====================================================================================
+// k_page_scan — one wave per chunk: running sums over its pages of the non-null counts (dense
+// value index of each page's first value) and, for strings, of the char bytes; checks that
+// bool/string pages hold exactly the bytes their values need.
+// =====================================================================================
+__global__ __launch_bounds__(64) void k_page_scan(const ChunkRec* __restrict__ chunks, u32 n_chunks,
+                                                  const PageRec* __restrict__ pages, PageDyn* __restrict__ page_dyn,
+                                                  ChunkDyn* __restrict__ chunk_dyn, int* __restrict__ status) {
+    const u32 c = blockIdx.x;
+    if (c >= n_chunks) return;
+    const ChunkRec C = chunks[c];
+    const u32 lane = threadIdx.x;
+    u64 run_vals = 0, run_chars = 0;
+    for (u32 base = 0; base < C.n_pages; base += 64) {
+        const u32 pi = base + lane;
+        u64 nn = 0, chars = 0;
+        if (pi < C.n_pages) {
+            const PageRec P = pages[C.first_page + pi];
+            nn = C.max_def > 0 ? page_dyn[C.first_page + pi].nn : P.num_values;
+            if (C.phys_type == PT_BYTE_ARRAY) {
+                if (4 * nn > P.val_len) set_status(status, ST_CORRUPT, C.first_page + pi);
+                else chars = P.val_len - 4 * nn;
+            } else if (C.phys_type == PT_BOOLEAN) {
+                const u64 need = (nn + 7) / 8;
+                if (P.val_len < need) set_status(status, ST_CORRUPT, C.first_page + pi);
+                else if (P.val_len > need && pi + 1 < C.n_pages) set_status(status, ST_NONCANONICAL, C.first_page + pi);
+            }
+        }
+        // inclusive wave scans
+        u64 sv = nn, sc = chars;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u64 tv = __shfl_up(sv, d), tc = __shfl_up(sc, d);
+            if (lane >= (u32)d) { sv += tv; sc += tc; }
+        }
+        if (pi < C.n_pages) {
+            page_dyn[C.first_page + pi].val_off = run_vals + sv - nn;
+            page_dyn[C.first_page + pi].char_off = run_chars + sc - chars;
+        }
+        run_vals += __shfl(sv, 63);
+        run_chars += __shfl(sc, 63);
+    }
+    if (lane == 0) {
+        // a required fixed-width Read takes pg.N values from the stream, however the pages split them
+        if (C.max_def == 0 && C.width_bytes) run_vals = C.req_values;
+        chunk_dyn[c].n_values = run_vals;
+        chunk_dyn[c].chars = run_chars;
+        if (C.phys_type == PT_BYTE_ARRAY) {
+            if (run_chars > 0x7fffffffull) set_status(status, ST_UNSUPPORTED, c);
+            else ((int32_t*)C.offsets)[run_vals] = (int32_t)run_chars;
+        }
+        // binary.Read of n_values*w bytes from the concatenated values regions (io.ReadFull)
+        if (C.width_bytes > 0 && run_vals * C.width_bytes > C.stream_len) set_status(status, ST_CORRUPT, c);
+    }
+}
+
+// =====================================================================================
+// k_bools — PLAIN booleans: bit i%8 of byte i/8, LSB first, restarting at a byte boundary on every
+// page (parquet.go:465-471).  One thread produces 16 output bytes.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_bools(const u8* __restrict__ src_base, const PageRec* __restrict__ pages,
+                                               const u32* __restrict__ page_ids, const u32* __restrict__ btile_prefix,
+                                               u32 n_bpages, const ChunkRec* __restrict__ chunks,
+                                               const PageDyn* __restrict__ page_dyn) {
+    const u32 bt = blockIdx.x;
+    const u32 k = find_owner(btile_prefix, n_bpages, bt);
+    const u32 pg = page_ids[k];
+    const PageRec P = pages[pg];
+    const ChunkRec C = chunks[P.chunk];
+    const PageDyn D = page_dyn[pg];
+    const u64 count = C.max_def > 0 ? D.nn : P.num_values;
+    const u64 i0 = (u64)(bt - btile_prefix[k]) * BT + threadIdx.x * 16;
+    if (i0 >= count) return;
+    const u8* s = src_base + P.val_src_off + (i0 >> 3);
+    const u32 bits = (u32)s[0] | (i0 + 8 < count ? (u32)s[1] << 8 : 0);
+    u8* dst = C.values + D.val_off + i0;
+    const u32 n = count - i0 < 16 ? (u32)(count - i0) : 16;
+    if (n == 16) {
+        u32x4 v;
+        // spread 4 bits into 4 bytes: multiply trick on nibbles
+        auto spread = [](u32 nib) { return ((nib & 1) | ((nib & 2) << 7) | ((nib & 4) << 14) | ((nib & 8) << 21)); };
+        v.x = spread(bits & 15); v.y = spread((bits >> 4) & 15); v.z = spread((bits >> 8) & 15); v.w = spread((bits >> 12) & 15);
+        *(u32x4_u*)dst = v;
+    } else {
+        for (u32 q = 0; q < n; q++) dst[q] = (bits >> q) & 1;
+    }
+}
+
+// =====================================================================================
+// k_str_gather — copies the characters of PLAIN BYTE_ARRAY values into the dense chars array.
+// One thread produces 16 output bytes: it finds the string holding its first byte in the offsets
+// array, then walks forward.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_str_gather(const u8* __restrict__ src_base, const PageRec* __restrict__ pages,
+                                                    const u32* __restrict__ page_ids, const u32* __restrict__ stile_prefix,
+                                                    u32 n_spages, const ChunkRec* __restrict__ chunks,
+                                                    const PageDyn* __restrict__ page_dyn) {
+    const u32 st = blockIdx.x;
+    const u32 k = find_owner(stile_prefix, n_spages, st);
+    const u32 pg = page_ids[k];
+    const PageRec P = pages[pg];
+    const ChunkRec C = chunks[P.chunk];
+    const PageDyn D = page_dyn[pg];
+    const u64 nn = C.max_def > 0 ? D.nn : P.num_values;
+    if (4 * nn > P.val_len) return;
+    if (nn == 0) return;
+    const u64 page_chars = P.val_len - 4 * nn;
+    const u64 x_rel = (u64)(st - stile_prefix[k]) * ST + threadIdx.x * 16;
+    if (x_rel >= page_chars) return;
+    const int32_t* offs = (const int32_t*)C.offsets;
+    const u64 x0 = D.char_off + x_rel;  // chunk-level char index
+    // last string s in [val_off, val_off + nn) with offs[s] <= x0
+    u64 a = D.val_off, b = D.val_off + nn;
+    while (b - a > 1) { const u64 mid = (a + b) >> 1; if ((u64)offs[mid] <= x0) a = mid; else b = mid; }
+    u64 s = a;
+    const u64 s_end = D.val_off + nn;
+    u64 next_off = s + 1 < s_end ? (u64)offs[s + 1] : D.char_off + page_chars;
+    const u8* src = src_base + P.val_src_off;
+    const u32 n = page_chars - x_rel < 16 ? (u32)(page_chars - x_rel) : 16;
+    u64 lo = 0, hi = 0;
+    for (u32 q = 0; q < n; q++) {
+        const u64 x = x0 + q;
+        while (next_off <= x && s + 1 < s_end) { s++; next_off = s + 1 < s_end ? (u64)offs[s + 1] : D.char_off + page_chars; }
+        // char index x of the chunk is byte (x - char_off) + 4*(strings started so far in the page)
+        const u64 v = src[(x - D.char_off) + 4 * (s - D.val_off + 1)];
+        if (q < 8) lo |= v << (8 * q); else hi |= v << (8 * (q - 8));
+    }
+    u8* dst = C.chars + x0;
+    if (n == 16) {
+        u32x4 v;
+        v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
+        *(u32x4_u*)dst = v;
+    } else {
+        for (u32 q = 0; q < n; q++) dst[q] = (u8)(q < 8 ? lo >> (8 * q) : hi >> (8 * (q - 8)));
+    }
+}
+
+// Checks after the string chain: every page must hold exactly as many values as its levels say and
+// end on its last byte.
+__global__ void k_str_check(const Region* __restrict__ regions, u32 n_regions, const RegionTotal* __restrict__ totals,
+                            const PageRec* __restrict__ pages, const ChunkRec* __restrict__ chunks,
+                            const PageDyn* __restrict__ page_dyn, int* __restrict__ status) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_regions) return;
+    const Region R = regions[r];
+    const PageRec P = pages[R.page];
+    const ChunkRec C = chunks[P.chunk];
+    const u64 want = C.max_def > 0 ? page_dyn[R.page].nn : P.num_values;
+    if (totals[r].err) return;
+    if (totals[r].cnt < want) set_status(status, ST_CORRUPT, R.page);
+    else if (totals[r].cnt > want) set_status(status, ST_NONCANONICAL, R.page);
+}
+
+// =====================================================================================
+// Validity bitmap and per-row offsets.  A row starts at every level with rep == 0 (every level when
+// the column is not repeated); its value offset is the number of def == max_def before it.
+//   k_rows_count   per tile of RT levels: row starts and non-null counts (+ validity words)
+//   k_rows_scan    one wave per chunk: exclusive scan of the tile counts
+//   k_rows_write   per tile: writes row_level_off / row_value_off
+// =====================================================================================
+static __device__ __forceinline__ u32 eq_mask16(u32x4 v, u32 level) {
+    u32 m = 0;
+    const u32 wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) m |= (u32)(((wds[i] >> (8 * b)) & 0xFF) == level) << (4 * i + b);
+    return m;
+}
+
+static __device__ __forceinline__ u32x4 load16_guarded(const u8* p, u64 i, u64 n) {
+    // p is 16-byte aligned at i == 0 and i % 16 == 0
+    if (i + 16 <= n) return *(const u32x4*)(p + i);
+    u32 wds[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // 0xFF never equals a level <= 8 bits wide that counts
+    for (u32 k = 0; i + k < n && k < 16; k++) wds[k >> 2] = (wds[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((u32)p[i + k] << (8 * (k & 3)));
+    u32x4 v; v.x = wds[0]; v.y = wds[1]; v.z = wds[2]; v.w = wds[3];
+    return v;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunks, const u32* __restrict__ rtile_prefix,
+                                              const u32* __restrict__ chunk_ids, u32 n_rchunks,
+                                              RowTile* __restrict__ tiles) {
+    __shared__ u32 s_rows[4], s_vals[4];
+    const u32 rt = blockIdx.x;
+    const u32 k = find_owner(rtile_prefix, n_rchunks, rt);
+    const ChunkRec C = chunks[chunk_ids[k]];
+    const u64 n = C.n_levels;
+    const u64 i0 = (u64)(rt - rtile_prefix[k]) * RT + threadIdx.x * 16;
+    u32 valid = 0, starts = 0;
+    if (i0 < n) {
+        const u32 in_range = n - i0 >= 16 ? 0xFFFFu : (1u << (n - i0)) - 1;
+        valid = eq_mask16(load16_guarded(C.defs, i0, n), (u32)C.max_def) & in_range;
+        starts = C.max_rep > 0 ? eq_mask16(load16_guarded(C.reps, i0, n), 0) & in_range : in_range;
+    }
+    if (!WRITE) {
+        // validity bitmap: 16 bits per thread
+        if (i0 < n) ((unsigned short*)C.validity)[i0 >> 4] = (unsigned short)valid;
+    }
+    // block-wide exclusive scan of (row starts, valid)
+    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u32 r = __popc(starts), v = __popc(valid);
+    u32 sr = r, sv = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 tr = __shfl_up(sr, d), tv = __shfl_up(sv, d);
+        if (lane >= (u32)d) { sr += tr; sv += tv; }
+    }
+    if (lane == 63) { s_rows[wv] = sr; s_vals[wv] = sv; }
+    __syncthreads();
+    u32 br = 0, bv = 0, tot_r = 0, tot_v = 0;
+    for (u32 q = 0; q < 4; q++) {
+        if (q < wv) { br += s_rows[q]; bv += s_vals[q]; }
+        tot_r += s_rows[q]; tot_v += s_vals[q];
+    }
+    if (!WRITE) {
+        if (threadIdx.x == 0) { tiles[rt].rows = tot_r; tiles[rt].vals = tot_v; }
+        return;
+    }
+    u64 row = tiles[rt].row_base + br + sr - r;
+    u64 val = tiles[rt].val_base + bv + sv - v;
+    u64* rl = (u64*)C.row_level_off;
+    u64* rv = (u64*)C.row_value_off;
+    u32 m = starts;
+    while (m) {
+        const u32 b = __ffs(m) - 1;
+        m &= m - 1;
+        rl[row] = i0 + b;
+        rv[row] = val + __popc(valid & ((1u << b) - 1));
+        row++;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_rows_scan(const ChunkRec* __restrict__ chunks, const u32* __restrict__ rtile_prefix,
+                                                  const u32* __restrict__ chunk_ids, u32 n_rchunks,
+                                                  RowTile* __restrict__ tiles, ChunkDyn* __restrict__ chunk_dyn) {
+    const u32 k = blockIdx.x;
+    if (k >= n_rchunks) return;
+    const u32 c = chunk_ids[k];
+    const ChunkRec C = chunks[c];
+    const u32 t0 = rtile_prefix[k], t1 = rtile_prefix[k + 1];
+    const u32 lane = threadIdx.x;
+    u64 run_r = 0, run_v = 0;
+    for (u32 base = t0; base < t1; base += 64) {
+        const u32 t = base + lane;
+        u64 r = 0, v = 0;
+        if (t < t1) { r = tiles[t].rows; v = tiles[t].vals; }
+        u64 sr = r, sv = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u64 tr = __shfl_up(sr, d), tv = __shfl_up(sv, d);
+            if (lane >= (u32)d) { sr += tr; sv += tv; }
+        }
+        if (t < t1) { tiles[t].row_base = run_r + sr - r; tiles[t].val_base = run_v + sv - v; }
+        run_r += __shfl(sr, 63);
+        run_v += __shfl(sv, 63);
+    }
+    if (lane == 0) {
+        chunk_dyn[c].n_rows = run_r;
+        ((u64*)C.row_level_off)[run_r] = C.n_levels;
+        ((u64*)C.row_value_off)[run_r] = run_v;
+    }
+}
+
+// Per-page non-null counts as int64 (the `sizes` slice of DoRead).
+__global__ void k_page_sizes(const ChunkRec* __restrict__ chunks, const PageRec* __restrict__ pages, u32 n_pages,
+                             const PageDyn* __restrict__ page_dyn) {
+    const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pages) return;
+    const PageRec P = pages[p];
+    const ChunkRec C = chunks[P.chunk];
+    ((int64_t*)C.page_nonnull)[p - C.first_page] = C.max_def > 0 ? (int64_t)page_dyn[p].nn : (int64_t)P.num_values;
+}
+
+// =====================================================================================
+// launch wrappers (called from pqd_api.cpp)
+// =====================================================================================
+#define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32* blk_prefix, u32 n_segs, u32 n_blocks,
+                       u32 max_grid) {
+    if (n_blocks == 0) return hipSuccess;
+    const u32 grid = n_blocks < max_grid ? n_blocks : max_grid;
+    hipLaunchKernelGGL(k_copy, dim3(grid), dim3(CP_THREADS), 0, st, src, segs, blk_prefix, n_segs, n_blocks);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const Region* regions, const u32* tile_prefix,
+                        u32 n_regions, u32 n_tiles, ExitRec* exit_tbl, TileEntry* tile_entry, RegionTotal* totals,
+                        RunRec* run_tbl, u32* otile_first_run, const PageDyn* page_dyn, int* status, int phase) {
+    if (n_regions == 0 || n_tiles == 0) return hipSuccess;
+    if (phase == 0) {
+        if (kind == KIND_LEVELS)
+            hipLaunchKernelGGL((k_chain<KIND_LEVELS, false>), dim3(n_tiles), dim3(CH_THREADS), 0, st, src, regions, tile_prefix,
+                               n_regions, exit_tbl, tile_entry, run_tbl, otile_first_run, page_dyn);
+        else
+            hipLaunchKernelGGL((k_chain<KIND_STRINGS, false>), dim3(n_tiles), dim3(CH_THREADS), 0, st, src, regions, tile_prefix,
+                               n_regions, exit_tbl, tile_entry, run_tbl, otile_first_run, page_dyn);
+        LAUNCH_CHECK();
+        const u32 g = (n_regions + 63) / 64;
+        if (kind == KIND_LEVELS)
+            hipLaunchKernelGGL((k_chain_resolve<KIND_LEVELS>), dim3(g), dim3(64), 0, st, src, regions, n_regions, exit_tbl,
+                               tile_entry, totals, status);
+        else
+            hipLaunchKernelGGL((k_chain_resolve<KIND_STRINGS>), dim3(g), dim3(64), 0, st, src, regions, n_regions, exit_tbl,
+                               tile_entry, totals, status);
+        LAUNCH_CHECK();
+    } else {
+        if (kind == KIND_LEVELS)
+            hipLaunchKernelGGL((k_chain<KIND_LEVELS, true>), dim3(n_tiles), dim3(CH_THREADS), 0, st, src, regions, tile_prefix,
+                               n_regions, exit_tbl, tile_entry, run_tbl, otile_first_run, page_dyn);
+        else
+            hipLaunchKernelGGL((k_chain<KIND_STRINGS, true>), dim3(n_tiles), dim3(CH_THREADS), 0, st, src, regions, tile_prefix,
+                               n_regions, exit_tbl, tile_entry, run_tbl, otile_first_run, page_dyn);
+        LAUNCH_CHECK();
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_prefix,
+                                u32 n_regions, u32 n_otiles, const RunRec* run_tbl, const u32* otile_first_run,
+                                const RegionTotal* totals, PageDyn* page_dyn) {
+    if (n_otiles == 0) return hipSuccess;
+    if (esz == 1)
+        hipLaunchKernelGGL((k_levels_expand<1>), dim3(n_otiles), dim3(256), 0, st, src, regions, otile_prefix, n_regions, run_tbl,
+                           otile_first_run, totals, page_dyn);
+    else if (esz == 2)
+        hipLaunchKernelGGL((k_levels_expand<2>), dim3(n_otiles), dim3(256), 0, st, src, regions, otile_prefix, n_regions, run_tbl,
+                           otile_first_run, totals, page_dyn);
+    else
+        hipLaunchKernelGGL((k_levels_expand<4>), dim3(n_otiles), dim3(256), 0, st, src, regions, otile_prefix, n_regions, run_tbl,
+                           otile_first_run, totals, page_dyn);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks, const PageRec* pages, u32 n_pages,
+                            PageDyn* page_dyn, ChunkDyn* chunk_dyn, int* status) {
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_page_scan, dim3(n_chunks), dim3(64), 0, st, chunks, n_chunks, pages, page_dyn, chunk_dyn, status);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_page_sizes, dim3((n_pages + 255) / 256), dim3(256), 0, st, chunks, pages, n_pages, page_dyn);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids, const u32* btile_prefix,
+                        u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn) {
+    if (n_btiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bools, dim3(n_btiles), dim3(256), 0, st, src, pages, page_ids, btile_prefix, n_bpages, chunks, page_dyn);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_str_gather(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids,
+                             const u32* stile_prefix, u32 n_spages, u32 n_stiles, const ChunkRec* chunks,
+                             const PageDyn* page_dyn, const Region* regions, u32 n_regions, const RegionTotal* totals,
+                             int* status) {
+    if (n_regions) {
+        hipLaunchKernelGGL(k_str_check, dim3((n_regions + 255) / 256), dim3(256), 0, st, regions, n_regions, totals, pages,
+                           chunks, page_dyn, status);
+        LAUNCH_CHECK();
+    }
+    if (n_stiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_str_gather, dim3(n_stiles), dim3(256), 0, st, src, pages, page_ids, stile_prefix, n_spages, chunks,
+                       page_dyn);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_prefix, const u32* chunk_ids, u32 n_rchunks,
+                       u32 n_rtiles, RowTile* tiles, ChunkDyn* chunk_dyn) {
+    if (n_rchunks == 0) return hipSuccess;
+    if (n_rtiles) {
+        hipLaunchKernelGGL((k_rows<false>), dim3(n_rtiles), dim3(256), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_rows_scan, dim3(n_rchunks), dim3(64), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles, chunk_dyn);
+    LAUNCH_CHECK();
+    if (n_rtiles) {
+        hipLaunchKernelGGL((k_rows<true>), dim3(n_rtiles), dim3(256), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles);
+        LAUNCH_CHECK();
+    }
+    return hipSuccess;
+}
+
+}  // namespace pqd

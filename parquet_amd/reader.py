@@ -1,0 +1,332 @@
+"""Host-side mirror of the parquetgen-generated reader over the C ABI of libpqdecode.so.
+
+Same names and meaning as the reference (cmd/parquetgen/gen/template.go:235-382):
+NewParquetReader → ParquetReader(buf); Rows() → rows(); Levels() → levels(); Next()/Scan() → next()/scan();
+Error() → error().  readRowGroup (template.go:320-351) becomes one batched decode call for all column
+chunks of the row group.  All decoding happens on the GPU through the library; this module only moves
+descriptors and fetches results.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+def _check(rc, ctx=None):
+    if rc != 0:
+        msg = ""
+        if ctx:
+            m = N.decode.pqd_last_error(ctx)
+            msg = m.decode() if m else ""
+        raise N.PqdError(rc, msg)
+
+
+class Context:
+    """pqd_ctx: one per reader (the reference reader is single goroutine)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = N.decode.pqd_create(device, C.byref(self._h))
+        if rc != 0:
+            raise N.PqdError(rc, "pqd_create(device=%d): no usable HIP device" % device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            N.decode.pqd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ParquetFile:
+    """pqd_file: footer + sequential page-header walk (no GPU needed)."""
+
+    def __init__(self, buf):
+        self._buf = buf  # keep alive: the file object points into it
+        self._arr = np.frombuffer(buf, np.uint8)
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        rc = N.decode.pqd_file_open(self._arr.ctypes.data, self._arr.size, C.byref(self._h), err, 256)
+        if rc != 0:
+            raise N.PqdError(rc, err.value.decode())
+        self.num_rows = N.decode.pqd_file_num_rows(self._h)
+        self.num_columns = N.decode.pqd_file_num_columns(self._h)
+        self.num_row_groups = N.decode.pqd_file_num_row_groups(self._h)
+        self.num_pages = N.decode.pqd_file_num_pages(self._h)
+        self.columns = []
+        for c in range(self.num_columns):
+            ci = N.ColumnInfo()
+            _check(N.decode.pqd_file_column(self._h, c, C.byref(ci)))
+            name = N.decode.pqd_file_column_path(self._h, c).decode()
+            self.columns.append((name, ci))
+
+    @property
+    def address(self):
+        return self._arr.ctypes.data
+
+    @property
+    def size(self):
+        return self._arr.size
+
+    def row_group_rows(self, rg):
+        return N.decode.pqd_file_row_group_rows(self._h, rg)
+
+    def descriptors(self, rg_first, rg_count):
+        """(chunk descriptor array, page descriptor array) for a range of row groups (copies)."""
+        cp, pp = C.POINTER(N.ChunkDesc)(), C.POINTER(N.PageDesc)()
+        nc, np_ = C.c_size_t(), C.c_size_t()
+        _check(N.decode.pqd_file_descriptors(self._h, rg_first, rg_count, C.byref(cp), C.byref(nc), C.byref(pp), C.byref(np_)))
+        chunks = (N.ChunkDesc * nc.value)()
+        pages = (N.PageDesc * max(np_.value, 1))()
+        C.memmove(chunks, cp, C.sizeof(N.ChunkDesc) * nc.value)
+        if np_.value:
+            C.memmove(pages, pp, C.sizeof(N.PageDesc) * np_.value)
+        return chunks, nc.value, pages, np_.value
+
+    def page_header(self, i):
+        out = (C.c_int32 * 8)()
+        pos = C.c_int64()
+        _check(N.decode.pqd_file_page_header(self._h, i, out, C.byref(pos)))
+        keys = ("type", "uncompressed_page_size", "compressed_page_size", "num_values", "encoding",
+                "definition_level_encoding", "repetition_level_encoding", "header_len")
+        d = dict(zip(keys, list(out)))
+        d["pos"] = pos.value
+        return d
+
+    def chunk_meta(self, rg, chunk):
+        out = (C.c_int64 * 6)()
+        _check(N.decode.pqd_file_chunk_meta(self._h, rg, chunk, out))
+        return dict(zip(("column", "num_values", "total_compressed_size", "start_pos", "first_page", "n_pages"), list(out)))
+
+    def chunk_codec(self, rg, chunk):
+        return N.decode.pqd_file_chunk_codec(self._h, rg, chunk)
+
+    def close(self):
+        if self._h:
+            N.decode.pqd_file_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DTYPES = {N.INT32: np.int32, N.INT64: np.int64, N.FLOAT: np.float32, N.DOUBLE: np.float64}
+
+
+class Plan:
+    """pqd_plan: a batch of column chunks planned for decode."""
+
+    def __init__(self, ctx, chunks, n_chunks, pages, n_pages, src_host_addr, src_len):
+        self.ctx = ctx
+        self._chunks = chunks
+        self.n_chunks = n_chunks
+        self._h = C.c_void_p()
+        rc = N.decode.pqd_plan_create(ctx.handle, chunks, n_chunks, pages, n_pages, src_host_addr, src_len, C.byref(self._h))
+        _check(rc, ctx.handle)
+
+    def run(self, src_device_addr):
+        _check(N.decode.pqd_plan_run(self._h, src_device_addr), self.ctx.handle)
+
+    def sync(self):
+        _check(N.decode.pqd_plan_sync(self._h), self.ctx.handle)
+
+    def last_ms(self):
+        a, b = C.c_float(), C.c_float()
+        _check(N.decode.pqd_plan_last_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def bytes(self):
+        i, o, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(N.decode.pqd_plan_bytes(self._h, C.byref(i), C.byref(o), C.byref(c)))
+        return i.value, o.value, c.value
+
+    def info(self, chunk):
+        ci = N.ChunkInfo()
+        _check(N.decode.pqd_plan_chunk_info(self._h, chunk, C.byref(ci)))
+        return ci
+
+    def device_ptr(self, chunk, which):
+        return N.decode.pqd_plan_device_ptr(self._h, chunk, which)
+
+    def fetch(self, chunk, which, dtype=np.uint8):
+        ci = self.info(chunk)
+        sizes = {
+            N.OUT_DEFS: ci.n_levels, N.OUT_REPS: ci.n_levels, N.OUT_VALUES: ci.value_bytes,
+            N.OUT_OFFSETS: (ci.n_values + 1) * 4, N.OUT_CHARS: ci.chars_bytes,
+            N.OUT_VALIDITY: (ci.n_levels + 7) // 8, N.OUT_PAGE_NONNULL: ci.n_pages * 8,
+            N.OUT_ROW_LEVEL_OFF: (ci.n_rows + 1) * 8, N.OUT_ROW_VALUE_OFF: (ci.n_rows + 1) * 8,
+        }
+        if not self.device_ptr(chunk, which):
+            return np.zeros(0, dtype)
+        buf = np.zeros(max(sizes[which], 1), np.uint8)
+        n = N.decode.pqd_plan_fetch(self._h, chunk, which, buf.ctypes.data, buf.size)
+        if n < 0:
+            _check(int(n), self.ctx.handle)
+        return buf[:n].view(dtype)
+
+    def column(self, chunk):
+        """All decoded arrays of one chunk as a dict of numpy arrays (the Field's vals / Defs / Reps)."""
+        cd = self._chunks[chunk]
+        out = {"defs": None, "reps": None}
+        if cd.max_def > 0:
+            out["defs"] = self.fetch(chunk, N.OUT_DEFS)
+            out["validity"] = self.fetch(chunk, N.OUT_VALIDITY)
+            out["row_level_off"] = self.fetch(chunk, N.OUT_ROW_LEVEL_OFF, np.int64)
+            out["row_value_off"] = self.fetch(chunk, N.OUT_ROW_VALUE_OFF, np.int64)
+        if cd.max_rep > 0:
+            out["reps"] = self.fetch(chunk, N.OUT_REPS)
+        out["sizes"] = self.fetch(chunk, N.OUT_PAGE_NONNULL, np.int64)
+        if cd.phys_type == N.BYTE_ARRAY:
+            out["offsets"] = self.fetch(chunk, N.OUT_OFFSETS, np.int32)
+            out["chars"] = self.fetch(chunk, N.OUT_CHARS)
+        elif cd.phys_type == N.BOOLEAN:
+            out["values"] = self.fetch(chunk, N.OUT_VALUES)
+        else:
+            out["values"] = self.fetch(chunk, N.OUT_VALUES, _DTYPES[cd.phys_type])
+        return out
+
+    def close(self):
+        if self._h:
+            N.decode.pqd_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode_host(ctx, chunks, n_chunks, pages, n_pages, src_addr, src_len):
+    """pqd_decode: host bytes in → synced plan with results in HBM."""
+    pl = Plan.__new__(Plan)
+    pl.ctx, pl._chunks, pl.n_chunks, pl._h = ctx, chunks, n_chunks, C.c_void_p()
+    rc = N.decode.pqd_decode(ctx.handle, chunks, n_chunks, pages, n_pages, src_addr, src_len, C.byref(pl._h))
+    if rc != 0:
+        m = N.decode.pqd_last_error(ctx.handle)
+        pl.close()
+        raise N.PqdError(rc, m.decode() if m else "")
+    return pl
+
+
+def rle_decode(ctx, width, block, max_values, elem_size=1):
+    """rle.Read for one level block (int32 length + runs): (values, number of values in the block)."""
+    dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[elem_size]
+    out = np.zeros(max(max_values, 1), dt)
+    n = C.c_int64()
+    block = bytes(block)
+    rc = N.decode.pqd_rle_decode(ctx.handle, width, block, len(block), elem_size, out.ctypes.data, max_values, C.byref(n))
+    _check(rc, ctx.handle)
+    return out[:min(n.value, max_values)], n.value
+
+
+class Levels:
+    """template.go:295-299"""
+
+    def __init__(self, name, defs, reps):
+        self.name, self.defs, self.reps = name, defs, reps
+
+
+class ParquetReader:
+    """NewParquetReader (template.go:235-270): reads the footer, then the first row group."""
+
+    def __init__(self, buf, device=0, ctx=None):
+        self._file = ParquetFile(buf)
+        self._ctx = ctx or Context(device)
+        self.field_names = [n for n, _ in self._file.columns]
+        self._rows = self._file.num_rows
+        self._cursor = 0
+        self._rg_next = 0
+        self._rg_cursor = 0
+        self._rg_count = 0
+        self._err = None
+        self.fields = {}
+        self._row_pos = {}
+        self._read_row_group()
+
+    def rows(self):
+        return self._rows
+
+    def error(self):
+        return self._err
+
+    def _read_row_group(self):
+        """readRowGroup (template.go:320-351): every column chunk of the next row group, one batch."""
+        self._rg_cursor = 0
+        if self._rg_next >= self._file.num_row_groups:
+            self._rg_count = 0
+            return
+        g = self._rg_next
+        chunks, nc, pages, npg = self._file.descriptors(g, 1)
+        plan = decode_host(self._ctx, chunks, nc, pages, npg, self._file.address, self._file.size)
+        try:
+            self.fields = {}
+            for c in range(nc):
+                name = self._file.columns[chunks[c].column][0]
+                self.fields[name] = plan.column(c)
+                self.fields[name]["desc"] = (chunks[c].phys_type, chunks[c].max_def, chunks[c].max_rep)
+        finally:
+            plan.close()
+        self._row_pos = {n: 0 for n in self.fields}
+        self._rg_count = self._file.row_group_rows(g)
+        self._rg_next += 1
+
+    def levels(self):
+        """Levels (template.go:301-314) of the row group currently held."""
+        out = []
+        for name in self.field_names:
+            f = self.fields.get(name)
+            d = f["defs"] if f is not None else None
+            r = f["reps"] if f is not None else None
+            out.append(Levels(name, d, r))
+        return out
+
+    def next(self):
+        """Next (template.go:357-371)."""
+        if self._err is None and self._cursor >= self._rows:
+            return False
+        if self._rg_cursor >= self._rg_count:
+            try:
+                self._read_row_group()
+            except N.PqdError as e:
+                self._err = e
+                return False
+        self._cursor += 1
+        self._rg_cursor += 1
+        return True
+
+    def scan(self):
+        """Scan (template.go:373-382): the current row as {column: (values, defs, reps)}; the slices are the
+        levels and values the generated write function would consume for this row."""
+        if self._err is not None:
+            return None
+        row = {}
+        for name in self.field_names:
+            f = self.fields[name]
+            r = self._row_pos[name]
+            ptype, max_def, _ = f["desc"]
+            if max_def == 0:
+                v0, v1, l0, l1 = r, r + 1, 0, 0
+            else:
+                l0, l1 = f["row_level_off"][r], f["row_level_off"][r + 1]
+                v0, v1 = f["row_value_off"][r], f["row_value_off"][r + 1]
+            if ptype == N.BYTE_ARRAY:
+                o = f["offsets"]
+                vals = [f["chars"][o[i]:o[i + 1]].tobytes() for i in range(v0, v1)]
+            else:
+                vals = f["values"][v0:v1]
+            row[name] = (vals, f["defs"][l0:l1] if max_def else None, f["reps"][l0:l1] if f["reps"] is not None else None)
+            self._row_pos[name] = r + 1
+        return row

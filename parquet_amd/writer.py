@@ -1,0 +1,163 @@
+"""Synthetic-file writer (libpqsynth.so): files laid out exactly as parsyl/parquet writes them with the
+`Uncompressed` option.  Support code for tests and benchmarks, not part of the decode path.
+
+Mirrors the write side of the generated API loosely: columns are declared like the generated
+`Fields()` (path + repetition `Types`, cmd/parquetgen/gen/template_optional.go:15-22), a row group
+corresponds to one `ParquetWriter.Write()` call and pages to the chained writers of `MaxPageSize`
+rows (template.go:164-215).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+REQUIRED, OPTIONAL, REPEATED = 0, 1, 2
+UINT_32, UINT_64, UTF8 = 13, 14, 0
+
+
+def bits_len(v):
+    return int(v).bit_length()
+
+
+class Column:
+    def __init__(self, path, phys_type, types, converted_type=-1):
+        self.path = path
+        self.phys_type = phys_type
+        self.types = list(types)
+        self.converted_type = converted_type
+        self.max_def = sum(1 for t in self.types if t in (OPTIONAL, REPEATED))
+        self.max_rep = sum(1 for t in self.types if t == REPEATED)
+
+
+class ParquetWriter:
+    def __init__(self, columns, stats=True):
+        self.columns = list(columns)
+        self._w = N.synth.pqw_create(1 if stats else 0)
+        self._open = False
+        for c in self.columns:
+            t = (C.c_int32 * len(c.types))(*c.types)
+            rc = N.synth.pqw_add_column(self._w, c.path.encode(), c.phys_type, c.converted_type, t, len(c.types))
+            if rc < 0:
+                raise ValueError("bad column %r" % c.path)
+
+    def begin_row_group(self):
+        assert N.synth.pqw_begin_row_group(self._w) == 0
+        self._open = True
+
+    def end_row_group(self, num_rows):
+        assert N.synth.pqw_end_row_group(self._w, num_rows) == 0
+        self._open = False
+
+    def write_page(self, col, values, defs=None, reps=None, offsets=None):
+        """One data page.  values: numpy array of the non-null values (fixed width), uint8 0/1 (bool),
+        or the concatenated chars with `offsets` (strings)."""
+        c = self.columns[col]
+        values = np.ascontiguousarray(values)
+        if c.phys_type == N.BYTE_ARRAY:
+            offsets = np.ascontiguousarray(offsets, np.int32)
+            n_values = offsets.size - 1
+            values = values.view(np.uint8) if values.size else np.zeros(1, np.uint8)
+        elif c.phys_type == N.BOOLEAN:
+            values = values.astype(np.uint8)
+            n_values = values.size
+        else:
+            want = 4 if c.phys_type in (N.INT32, N.FLOAT) else 8
+            assert values.dtype.itemsize == want, (values.dtype, c.path)
+            n_values = values.size
+        if c.max_def > 0:
+            defs = np.ascontiguousarray(defs, np.uint8)
+            n_levels = defs.size
+            dp = defs.ctypes.data
+        else:
+            n_levels, dp = n_values, None
+        rp = None
+        if c.max_rep > 0:
+            reps = np.ascontiguousarray(reps, np.uint8)
+            assert reps.size == n_levels
+            rp = reps.ctypes.data
+        op = offsets.ctypes.data if offsets is not None else None
+        vp = values.ctypes.data if values.size else None
+        rc = N.synth.pqw_write_page(self._w, col, dp, rp, n_levels, vp, n_values, op)
+        if rc != 0:
+            raise ValueError("pqw_write_page failed for %s" % c.path)
+
+    def write_raw_page(self, col, payload, num_values):
+        payload = bytes(payload)
+        buf = (C.c_uint8 * max(len(payload), 1)).from_buffer_copy(payload or b"\0")
+        rc = N.synth.pqw_write_raw_page(self._w, col, buf, len(payload), num_values)
+        if rc != 0:
+            raise ValueError("pqw_write_raw_page failed")
+
+    def finish(self):
+        assert N.synth.pqw_finish(self._w) == 0
+        n = C.c_int64()
+        p = N.synth.pqw_data(self._w, C.byref(n))
+        return C.string_at(p, n.value)
+
+    def finish_into(self, alloc):
+        """Like finish(), but copies the file into a buffer obtained from alloc(nbytes) → address."""
+        assert N.synth.pqw_finish(self._w) == 0
+        n = C.c_int64()
+        p = N.synth.pqw_data(self._w, C.byref(n))
+        dst = alloc(n.value)
+        C.memmove(dst, p, n.value)
+        return dst, n.value
+
+    def close(self):
+        if self._w:
+            N.synth.pqw_destroy(self._w)
+            self._w = None
+
+    def __del__(self):
+        self.close()
+
+
+def encode_levels(width, levels):
+    levels = np.ascontiguousarray(levels, np.uint8)
+    cap = levels.size * 2 + 64
+    out = np.zeros(cap, np.uint8)
+    n = N.synth.pqw_encode_levels(width, levels.ctypes.data if levels.size else None, levels.size, out.ctypes.data, cap)
+    assert n >= 0
+    return out[:n].tobytes()
+
+
+def write_flat_table(columns, data, rows_per_group, rows_per_page, stats=True):
+    """Writes flat (non-repeated) columns.  data[i] is either a numpy array (required column), or a
+    pair (values_of_all_rows, valid_mask) for an optional column; strings are lists of bytes/None."""
+    w = ParquetWriter(columns, stats=stats)
+    n_rows = None
+    for c, d in zip(columns, data):
+        n = len(d[0]) if isinstance(d, tuple) else len(d)
+        n_rows = n if n_rows is None else n_rows
+        assert n == n_rows
+    for g0 in range(0, max(n_rows, 1), rows_per_group):
+        g1 = min(n_rows, g0 + rows_per_group)
+        if g1 <= g0:
+            break
+        w.begin_row_group()
+        for ci, (c, d) in enumerate(zip(columns, data)):
+            for p0 in range(g0, g1, rows_per_page):
+                p1 = min(g1, p0 + rows_per_page)
+                if isinstance(d, tuple):
+                    vals, mask = d
+                    m = np.asarray(mask[p0:p1], bool)
+                    defs = m.astype(np.uint8) * c.max_def
+                else:
+                    vals, m, defs = d, None, None
+                if c.phys_type == N.BYTE_ARRAY:
+                    items = [vals[i] for i in range(p0, p1) if m is None or m[i - p0]]
+                    lens = np.array([len(s) for s in items], np.int64)
+                    offsets = np.zeros(len(items) + 1, np.int32)
+                    np.cumsum(lens, out=offsets[1:])
+                    chars = np.frombuffer(b"".join(items), np.uint8)
+                    w.write_page(ci, chars, defs=defs, offsets=offsets)
+                else:
+                    v = np.asarray(vals[p0:p1])
+                    if m is not None:
+                        v = v[m]
+                    w.write_page(ci, v, defs=defs)
+        w.end_row_group(g1 - g0)
+    out = w.finish()
+    w.close()
+    return out

@@ -150,7 +150,8 @@ def page_header(data):
 
 class Chunk:
     """Result of one Field.Read (one column chunk)."""
-    __slots__ = ("defs", "reps", "values", "n_values", "offsets", "sizes", "consumed", "error")
+    __slots__ = ("defs", "reps", "values", "n_values", "offsets", "sizes", "consumed", "error",
+                 "max_def", "max_rep", "phys_type")
 
 
 def read_chunk(file_bytes, pos, phys_type, max_def, max_rep, pg_n, pg_size):
