@@ -798,15 +798,18 @@ hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32
 hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const Region* regions, const u32* tile_prefix,
                         u32 n_regions, u32 n_tiles, ExitRec* exit_tbl, TileEntry* tile_entry, RegionTotal* totals,
                         RunRec* run_tbl, u32* otile_first_run, const PageDyn* page_dyn, int* status, int phase) {
-    if (n_regions == 0 || n_tiles == 0) return hipSuccess;
+    if (n_regions == 0) return hipSuccess;
     if (phase == 0) {
-        if (kind == KIND_LEVELS)
-            hipLaunchKernelGGL((k_chain<KIND_LEVELS, false>), dim3(n_tiles), dim3(CH_THREADS), 0, st, src, regions, tile_prefix,
-                               n_regions, exit_tbl, tile_entry, run_tbl, otile_first_run, page_dyn);
-        else
-            hipLaunchKernelGGL((k_chain<KIND_STRINGS, false>), dim3(n_tiles), dim3(CH_THREADS), 0, st, src, regions, tile_prefix,
-                               n_regions, exit_tbl, tile_entry, run_tbl, otile_first_run, page_dyn);
-        LAUNCH_CHECK();
+        if (n_tiles) {
+            if (kind == KIND_LEVELS)
+                hipLaunchKernelGGL((k_chain<KIND_LEVELS, false>), dim3(n_tiles), dim3(CH_THREADS), 0, st, src, regions, tile_prefix,
+                                   n_regions, exit_tbl, tile_entry, run_tbl, otile_first_run, page_dyn);
+            else
+                hipLaunchKernelGGL((k_chain<KIND_STRINGS, false>), dim3(n_tiles), dim3(CH_THREADS), 0, st, src, regions, tile_prefix,
+                                   n_regions, exit_tbl, tile_entry, run_tbl, otile_first_run, page_dyn);
+            LAUNCH_CHECK();
+        }
+        // the hop kernel also runs for empty regions: it writes their (zero) totals
         const u32 g = (n_regions + 63) / 64;
         if (kind == KIND_LEVELS)
             hipLaunchKernelGGL((k_chain_resolve<KIND_LEVELS>), dim3(g), dim3(64), 0, st, src, regions, n_regions, exit_tbl,
@@ -815,7 +818,7 @@ hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const Region* r
             hipLaunchKernelGGL((k_chain_resolve<KIND_STRINGS>), dim3(g), dim3(64), 0, st, src, regions, n_regions, exit_tbl,
                                tile_entry, totals, status);
         LAUNCH_CHECK();
-    } else {
+    } else if (n_tiles) {
         if (kind == KIND_LEVELS)
             hipLaunchKernelGGL((k_chain<KIND_LEVELS, true>), dim3(n_tiles), dim3(CH_THREADS), 0, st, src, regions, tile_prefix,
                                n_regions, exit_tbl, tile_entry, run_tbl, otile_first_run, page_dyn);

@@ -1,0 +1,384 @@
+"""GPU parity tests: the HIP decoder (through the C ABI) against the CPU oracle, bit exact."""
+import numpy as np
+import pytest
+
+import helpers as H
+import oracle as O
+from parquet_amd import _native as N
+from parquet_amd import reader as R
+from parquet_amd.writer import Column, ParquetWriter, encode_levels, write_flat_table, REQUIRED, OPTIONAL, REPEATED
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = R.Context(0)
+    yield c
+    c.close()
+
+
+# ---------------------------------------------------------------- levels on their own (rle.Read)
+def _bitpacked_block(width, groups_bytes, n_groups):
+    body = bytes([(n_groups << 1) | 1]) + bytes(groups_bytes)
+    return len(body).to_bytes(4, "little") + body
+
+
+def test_reference_bitpack_vectors(ctx):
+    # internal/bitpack/bitpack_test.go:21-43 as single-group bit-packed runs
+    cases = [(1, [0, 1, 1, 0, 0, 1, 1, 1], [0b11100110]),
+             (2, [0, 1, 2, 0, 0, 1, 2, 2], [0b00100100, 0b10100100]),
+             (3, [0, 1, 2, 3, 4, 5, 6, 7], [0b10001000, 0b11000110, 0b11111010]),
+             (4, [0, 2, 4, 7, 14, 15, 1, 0], [0x20, 0x74, 0xFE, 0x01])]
+    for w, ints, data in cases:
+        vals, n = R.rle_decode(ctx, w, _bitpacked_block(w, data, 1), 8)
+        assert n == 8 and vals.tolist() == ints
+
+
+def _mod(m, c):
+    return [i % m for i in range(c)]
+
+
+RLE_CASES = [(3, [4] * 100 + [5] * 100), (0, [0] * 10), (1, [0] * 17), (1, [1] * 17), (3, _mod(3, 100)),
+             (3, _mod(3, 103)), (1, [1]), (1, [1, 0, 1, 1, 0]), (2, [1, 2, 3]), (3, [1, 2, 7])]
+
+
+@pytest.mark.parametrize("width,vals", RLE_CASES)
+def test_reference_rle_round_trips(ctx, width, vals):
+    # internal/rle/rle_test.go:21-71
+    enc = O.rle_encode(width, vals)
+    want, _ = O.rle_read(width, enc)
+    got, n = R.rle_decode(ctx, width, enc, len(want))
+    assert n == len(want)
+    assert np.array_equal(got, want)
+    assert got[:len(vals)].tolist() == vals
+
+
+def test_old_writer_runs_of_one(ctx):
+    block = bytes([8, 0, 0, 0, 0x02, 0x01, 0x02, 0x00, 0x02, 0x01, 0x08, 0x00])
+    got, n = R.rle_decode(ctx, 1, block, 16)
+    assert n == 7 and got.tolist() == [1, 0, 1, 0, 0, 0, 0]
+
+
+def test_short_bitpacked_run_is_zero_padded(ctx):
+    got, n = R.rle_decode(ctx, 1, bytes([2, 0, 0, 0, (2 << 1) | 1, 0xFF]), 16)
+    assert n == 16 and got.tolist() == [1] * 8 + [0] * 8
+
+
+def test_malformed_blocks_return_errors(ctx):
+    for block in (bytes([1, 0, 0, 0, 0x03]), bytes([1, 0, 0, 0, 0x10]), bytes([1, 0, 0, 0, 0x80]), b"\x01\x00"):
+        with pytest.raises(O.OracleError):
+            O.rle_read(1, block)
+        with pytest.raises(N.PqdError) as e:
+            R.rle_decode(ctx, 1, block, 64)
+        assert e.value.code == N.E_CORRUPT
+
+
+def test_rle_value_byte_not_masked_and_multibyte_header(ctx):
+    got, n = R.rle_decode(ctx, 1, bytes([2, 0, 0, 0, 0x06, 0xFF]), 8)
+    assert got.tolist() == [255, 255, 255]
+    got, n = R.rle_decode(ctx, 2, bytes([3, 0, 0, 0, 0xD0, 0x0F, 0x03]), 2000)
+    assert n == 1000 and got.tolist() == [3] * 1000
+
+
+@pytest.mark.parametrize("width", [0, 1, 2, 3, 4])
+def test_random_level_blocks_reference_widths(ctx, width):
+    rng = np.random.default_rng(100 + width)
+    for n in (1, 7, 8, 9, 63, 64, 503, 504, 505, 513, 4000, 4096, 4097, 20000, 300000):
+        for p_run in (0.0, 0.5, 0.9, 0.999):
+            vals = rng.integers(0, max(1 << width, 1), n, dtype=np.uint8)
+            keep = rng.random(n) < p_run
+            idx = np.where(~keep)[0]
+            if len(idx):
+                # forward-fill to make runs
+                last = np.maximum.accumulate(np.where(~keep, np.arange(n), 0))
+                vals = vals[last]
+            enc = O.rle_encode(width, vals)
+            want, _ = O.rle_read(width, enc)
+            got, cnt = R.rle_decode(ctx, width, enc, len(want) + 5)
+            assert cnt == len(want), (n, p_run)
+            assert np.array_equal(got, want), (width, n, p_run)
+            # truncated request (fields.go:300,308 take [:NumValues])
+            got2, _ = R.rle_decode(ctx, width, enc, n)
+            assert np.array_equal(got2, vals)
+
+
+def _spec_encode(width, vals, rng):
+    """Hybrid block for any width 1..32 (Parquet format text): random mix of RLE and bit-packed runs."""
+    vals = np.asarray(vals, np.uint64)
+    out = bytearray()
+    i, n = 0, len(vals)
+    bw = (width + 7) // 8
+    while i < n:
+        j = i
+        while j < n and vals[j] == vals[i]:
+            j += 1
+        if j - i >= 8 or (rng.random() < 0.2):
+            h = (j - i) << 1
+            while h >= 0x80:
+                out.append((h & 0x7F) | 0x80)
+                h >>= 7
+            out.append(h)
+            out += int(vals[i]).to_bytes(bw, "little")
+            i = j
+        else:
+            g = int(rng.integers(1, 70))
+            cnt = min(g * 8, ((n - i) + 7) // 8 * 8)
+            g = cnt // 8
+            chunk = np.zeros(cnt, np.uint64)
+            m = min(cnt, n - i)
+            chunk[:m] = vals[i:i + m]
+            h = (g << 1) | 1
+            while h >= 0x80:
+                out.append((h & 0x7F) | 0x80)
+                h >>= 7
+            out.append(h)
+            acc = 0
+            for k, v in enumerate(chunk):
+                acc |= int(v) << (k * width)
+            out += acc.to_bytes(cnt * width // 8, "little")
+            i += m
+    return len(out).to_bytes(4, "little") + bytes(out)
+
+
+@pytest.mark.parametrize("width", list(range(1, 33)))
+def test_level_widths_1_to_32_spec_parity(ctx, width):
+    """Widths 5..32 have no reference behaviour (rle.New rejects > 4): parity here is against the
+    Parquet format text as restated by the oracle's pqo_rle_read_u32."""
+    rng = np.random.default_rng(200 + width)
+    n = 5000
+    vals = rng.integers(0, 1 << width, n, dtype=np.uint64)
+    vals[100:400] = vals[100]
+    vals[2000:2009] = vals[2000]
+    block = _spec_encode(width, vals, rng)
+    want, _ = O.rle_read_u32(width, block, n + 600)
+    assert np.array_equal(want[:n], vals.astype(np.uint32))
+    esz = 1 if width <= 8 else 2 if width <= 16 else 4
+    got, cnt = R.rle_decode(ctx, width, block, len(want), elem_size=esz)
+    assert cnt == len(want)
+    assert np.array_equal(got.astype(np.uint32), want)
+    if width <= 8:
+        want8, _ = O.rle_read(width, block)
+        assert np.array_equal(got, want8)
+
+
+# ---------------------------------------------------------------- whole files
+def test_flat_required_numeric(ctx):
+    # config "flat required int32/int64/float64", small pages + ragged tail
+    rng = np.random.default_rng(1)
+    cols = [Column("i32", N.INT32, [0]), Column("i64", N.INT64, [0]), Column("f64", N.DOUBLE, [0]),
+            Column("f32", N.FLOAT, [0]), Column("u32", N.INT32, [0], 13), Column("u64", N.INT64, [0], 14)]
+    for n, group, page in ((1, 10, 10), (1000, 1000, 1000), (10007, 4000, 999), (70000, 70000, 33333)):
+        buf = H.build_file(cols, n, group, page, rng)
+        H.check_file(buf, ctx)
+        H.check_file(buf, ctx, rg_batch=1)
+
+
+@pytest.mark.parametrize("p_null", [0.0, 0.1, 0.5, 1.0])
+def test_optional_numeric_and_strings(ctx, p_null):
+    rng = np.random.default_rng(int(p_null * 100) + 7)
+    cols = [Column("a", N.INT32, [1]), Column("b", N.INT64, [1]), Column("s", N.BYTE_ARRAY, [1]),
+            Column("t", N.BYTE_ARRAY, [0]), Column("d", N.DOUBLE, [1])]
+    buf = H.build_file(cols, 30011, 12000, 5000, rng, p_null=p_null, str_len=(8, 32), alphabet=(97, 123))
+    H.check_file(buf, ctx)
+
+
+def test_bools_across_page_boundaries(ctx):
+    # parquet_test.go:219-376: 3001 values at page sizes 2 / 3 / 3000
+    rng = np.random.default_rng(3)
+    cols = [Column("b", N.BOOLEAN, [0]), Column("ob", N.BOOLEAN, [1])]
+    for page in (2, 3, 7, 8, 9, 3000, 4096):
+        buf = H.build_file(cols, 3001, 3001, page, rng, p_null=0.4)
+        H.check_file(buf, ctx)
+    buf = H.build_file(cols, 100003, 100003, 50001, rng, p_null=0.1)
+    H.check_file(buf, ctx)
+
+
+def test_nested_repeated_person(ctx):
+    # README Person{Being{ID, Age*}, Username, Friends []Being}
+    rng = np.random.default_rng(4)
+    cols = [Column("being.id", N.INT32, [0, 0]), Column("being.age", N.INT32, [0, 1]),
+            Column("username", N.BYTE_ARRAY, [0]),
+            Column("friends.id", N.INT32, [2, 0]), Column("friends.age", N.INT32, [2, 1])]
+    buf = H.build_file(cols, 20000, 8000, 3000, rng, p_null=0.5)
+    o, g = H.check_file(buf, ctx)
+    assert o[(0, "friends.age")].max_def == 2 and o[(0, "friends.age")].max_rep == 1
+
+
+def test_dremel_document_and_deep_chain(ctx):
+    # cmd/parquetgen/dremel/testcases/doc schema (def <= 3, rep <= 2) and a 5-deep chain (width 3)
+    rng = np.random.default_rng(5)
+    cols = [Column("docid", N.INT64, [0]),
+            Column("links.backward", N.INT64, [1, 2]), Column("links.forward", N.INT64, [1, 2]),
+            Column("names.languages.code", N.BYTE_ARRAY, [2, 2, 0]),
+            Column("names.languages.country", N.BYTE_ARRAY, [2, 2, 1]),
+            Column("names.url", N.BYTE_ARRAY, [2, 1]),
+            Column("a.b.c.d.e", N.INT32, [1, 2, 1, 2, 1]),
+            Column("x.y.z.w.v.u.t", N.INT64, [2, 1, 2, 1, 2, 1, 1])]
+    buf = H.build_file(cols, 6000, 2500, 700, rng, p_null=0.25, str_len=(0, 12))
+    o, g = H.check_file(buf, ctx)
+    assert o[(0, "a.b.c.d.e")].max_def == 5 and o[(0, "x.y.z.w.v.u.t")].max_def == 7
+
+
+def test_dremel_paper_known_levels(ctx):
+    """cmd/parquetgen/dremel/dremel_test.go:77-84: the levels of the two Dremel-paper documents,
+    written with the reference encoder layout and read back through the GPU path."""
+    kat = [("links.backward", [1, 2], N.INT64, [1, 2, 2], [0, 0, 1]),
+           ("links.forward", [1, 2], N.INT64, [2, 2, 2, 2], [0, 1, 1, 0]),
+           ("names.languages.code", [2, 2, 0], N.BYTE_ARRAY, [2, 2, 1, 2, 1], [0, 2, 1, 1, 0]),
+           ("names.languages.country", [2, 2, 1], N.BYTE_ARRAY, [3, 2, 1, 3, 1], [0, 2, 1, 1, 0]),
+           ("names.url", [2, 1], N.BYTE_ARRAY, [2, 2, 1, 2], [0, 1, 1, 0])]
+    cols = [Column(p, t, types) for p, types, t, _, _ in kat]
+    w = ParquetWriter(cols)
+    w.begin_row_group()
+    for ci, (p, types, t, d, r) in enumerate(kat):
+        md = cols[ci].max_def
+        nv = sum(1 for x in d if x == md)
+        if t == N.INT64:
+            w.write_page(ci, np.arange(nv, dtype=np.int64) * 10, defs=d, reps=r)
+        else:
+            chars = np.frombuffer(b"ab" * nv, np.uint8)
+            w.write_page(ci, chars, defs=d, reps=r, offsets=np.arange(nv + 1, dtype=np.int32) * 2)
+    w.end_row_group(2)
+    buf = w.finish()
+    o, g = H.check_file(buf, ctx)
+    for p, types, t, d, r in kat:
+        assert g[(0, p)]["defs"].tolist() == d
+        assert g[(0, p)]["reps"].tolist() == r
+        assert len(g[(0, p)]["row_level_off"]) == 3  # two documents
+
+
+def test_strings_edge_cases(ctx):
+    rng = np.random.default_rng(6)
+    cols = [Column("s", N.BYTE_ARRAY, [0]), Column("o", N.BYTE_ARRAY, [1])]
+    # empty strings only, long strings (beyond the tabulated entry window), binary bytes, mixed
+    for lo, hi, n, page in ((0, 0, 5000, 1000), (0, 3, 20000, 7000), (100, 400, 3000, 1000),
+                            (1000, 6000, 200, 77), (0, 300, 9000, 2048)):
+        buf = H.build_file(cols, n, n, page, rng, p_null=0.2, str_len=(lo, hi))
+        H.check_file(buf, ctx)
+
+
+def test_tiny_and_empty_pages(ctx):
+    rng = np.random.default_rng(8)
+    cols = [Column("a", N.INT32, [1]), Column("s", N.BYTE_ARRAY, [1]), Column("b", N.BOOLEAN, [1]),
+            Column("r", N.INT64, [2])]
+    for page in (1, 2, 3, 5):
+        buf = H.build_file(cols, 200, 90, page, rng, p_null=0.5)
+        H.check_file(buf, ctx)
+
+
+def test_statistics_free_headers_and_all_null_pages(ctx):
+    rng = np.random.default_rng(9)
+    cols = [Column("a", N.INT32, [1]), Column("s", N.BYTE_ARRAY, [1])]
+    buf = H.build_file(cols, 5000, 5000, 1000, rng, p_null=1.0, stats=False)
+    o, g = H.check_file(buf, ctx)
+    assert g[(0, "a")]["values"].size == 0 and g[(0, "s")]["offsets"].tolist() == [0]
+
+
+def test_hand_built_old_format_level_block(ctx):
+    """A page whose def levels are RLE runs of length 1, as in _examples/via_parquet/people.parquet."""
+    cols = [Column("age", N.INT32, [1])]
+    w = ParquetWriter(cols, stats=False)
+    w.begin_row_group()
+    defs = [1, 0, 1, 1, 0, 0, 1, 0, 1, 1]
+    body = b"".join(bytes([0x02, d]) for d in defs)
+    vals = np.arange(sum(defs), dtype=np.int32) + 20
+    payload = len(body).to_bytes(4, "little") + body + vals.tobytes()
+    w.write_raw_page(0, payload, len(defs))
+    w.end_row_group(len(defs))
+    buf = w.finish()
+    o, g = H.check_file(buf, ctx)
+    assert g[(0, "age")]["defs"].tolist() == defs
+    assert g[(0, "age")]["values"].tolist() == vals.tolist()
+
+
+def test_corrupt_pages_return_errors_not_crashes(ctx):
+    cols = [Column("age", N.INT32, [1]), Column("s", N.BYTE_ARRAY, [0])]
+
+    def one(payload0, nv0, payload1, nv1):
+        w = ParquetWriter(cols, stats=False)
+        w.begin_row_group()
+        w.write_raw_page(0, payload0, nv0)
+        w.write_raw_page(1, payload1, nv1)
+        w.end_row_group(nv0)
+        return w.finish()
+
+    good_s = (3).to_bytes(4, "little") + b"abc"
+    good_a = bytes([2, 0, 0, 0, 0x02, 0x01]) + (7).to_bytes(4, "little")
+    buf = one(good_a, 1, good_s, 1)
+    H.check_file(buf, ctx)
+    cases = {
+        "levels shorter than num_values": one(bytes([2, 0, 0, 0, 0x02, 0x01]) + (7).to_bytes(4, "little"), 5, good_s, 1),
+        "level block longer than the page": one(bytes([200, 0, 0, 0, 0x02, 0x01]), 1, good_s, 1),
+        "truncated run header": one(bytes([1, 0, 0, 0, 0x80]) + b"\0" * 4, 1, good_s, 1),
+        "values shorter than the non-null count": one(bytes([2, 0, 0, 0, 0x06, 0x01]) + (7).to_bytes(4, "little"), 3, good_s, 1),
+        "negative string length": one(good_a, 1, (0xFFFFFFFF).to_bytes(4, "little") + b"abc", 1),
+        "string runs past the page": one(good_a, 1, (300).to_bytes(4, "little") + b"abc", 1),
+        "fewer strings than values": one(good_a, 1, good_s, 2),
+    }
+    # The reference does not fail on a final string whose declared length exceeds the bytes left: the
+    # short Read leaves the tail of the string zero (template_string.go:52-55).  The decoder reports it
+    # as corrupt instead of returning padding.
+    lenient = {"string runs past the page"}
+    for name, buf in cases.items():
+        pf = R.ParquetFile(buf)
+        o = H.oracle_file(buf, pf)
+        if name in lenient:
+            assert all(ch.error == 0 for ch in o.values()), name
+            assert o[(0, "s")].values.tobytes() == b"abc" + b"\0" * 297
+        else:
+            assert any(ch.error != 0 for ch in o.values()), name
+        with pytest.raises(N.PqdError) as e:
+            H.gpu_file(buf, ctx, pf=pf)
+        assert e.value.code in (N.E_CORRUPT, N.E_NONCANONICAL), (name, e.value.code)
+
+
+def test_reader_api_next_scan(ctx):
+    """NewParquetReader / Next / Scan / Rows / Levels through the Python mirror."""
+    rng = np.random.default_rng(10)
+    n = 500
+    ids = rng.integers(0, 1000, n).astype(np.int32)
+    age = rng.integers(0, 100, n).astype(np.int32)
+    am = rng.random(n) > 0.5
+    names = [b"user%d" % i for i in range(n)]
+    cols = [Column("id", N.INT32, [0]), Column("age", N.INT32, [1]), Column("name", N.BYTE_ARRAY, [0])]
+    buf = write_flat_table(cols, [ids, (age, am), names], 200, 60)
+    pr = R.ParquetReader(buf, ctx=ctx)
+    assert pr.rows() == n
+    lv = pr.levels()
+    assert [l.name for l in lv] == ["id", "age", "name"] and lv[0].defs is None
+    assert lv[1].defs.tolist() == am[:200].astype(np.uint8).tolist()
+    i = 0
+    while pr.next():
+        row = pr.scan()
+        assert row["id"][0].tolist() == [ids[i]]
+        assert row["age"][0].tolist() == ([age[i]] if am[i] else [])
+        assert row["name"][0] == [names[i]]
+        i += 1
+    assert i == n and pr.error() is None
+
+
+def test_full_size_pages_property(ctx):
+    """BASELINE size: 1M-row pages.  Size-independent property: a required fixed-width chunk equals the
+    concatenation of its pages' payload bytes; the def levels of an optional chunk expand back to the
+    validity mask they were encoded from; the dense values equal the non-null inputs."""
+    n, page = 3_000_000, 1_000_000
+    i32 = H.splitmix64(2, n).astype(np.uint32).view(np.int32)
+    i64 = H.splitmix64(3, n).view(np.int64)
+    f64 = (H.splitmix64(4, n) & np.uint64(0x7FEFFFFFFFFFFFFF)).view(np.float64)
+    mask = (H.splitmix64(5, n) % np.uint64(10)) != 0
+    opt = H.splitmix64(6, n).astype(np.uint32).view(np.int32)
+    cols = [Column("i32", N.INT32, [0]), Column("i64", N.INT64, [0]), Column("f64", N.DOUBLE, [0]),
+            Column("opt", N.INT32, [1])]
+    buf = write_flat_table(cols, [i32, i64, f64, (opt, mask)], n, page)
+    g = H.gpu_file(buf, ctx)
+    assert np.array_equal(g[(0, "i32")]["values"], i32)
+    assert np.array_equal(g[(0, "i64")]["values"], i64)
+    assert np.array_equal(g[(0, "f64")]["values"].view(np.uint64), f64.view(np.uint64))
+    assert np.array_equal(g[(0, "opt")]["defs"], mask.astype(np.uint8))
+    assert np.array_equal(g[(0, "opt")]["values"], opt[mask])
+    assert np.array_equal(g[(0, "opt")]["validity"], np.packbits(mask, bitorder="little"))
+    assert g[(0, "opt")]["sizes"].tolist() == [int(mask[i:i + page].sum()) for i in range(0, n, page)]
+    # and against the oracle on the optional chunk (seconds)
+    o = H.oracle_file(buf)
+    H.assert_chunk_equal(o[(0, "opt")], g[(0, "opt")], "opt")
