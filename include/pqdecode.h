@@ -127,6 +127,10 @@ int pqd_plan_sync(pqd_plan* plan);
 /* Device time of the last completed run in milliseconds (first kernel start → last kernel end),
  * and of its dominant kernel (the PLAIN value gather), both from HIP events on the ctx stream. */
 int pqd_plan_last_ms(pqd_plan* plan, float* total_ms, float* plain_copy_ms);
+/* The same for an earlier run: runs_back = 0 is the last run, 1 the one before, ... (the plan keeps
+ * the events of its last 256 runs, so a caller can queue many runs and read all their timings after
+ * one sync). */
+int pqd_plan_run_ms(pqd_plan* plan, int runs_back, float* total_ms, float* plain_copy_ms);
 /* Algorithmic bytes of one run: payload bytes read + decoded bytes the reference materialises
  * (defs, reps, values / bools / string offsets+chars); and the part moved by the value gather. */
 int pqd_plan_bytes(pqd_plan* plan, int64_t* bytes_in, int64_t* bytes_out, int64_t* plain_copy_bytes);

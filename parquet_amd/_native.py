@@ -60,6 +60,7 @@ DECODE_SYMBOLS = {
     "pqd_plan_run": (C.c_int, [_P, _P]),
     "pqd_plan_sync": (C.c_int, [_P]),
     "pqd_plan_last_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "pqd_plan_run_ms": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pqd_plan_bytes": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pqd_plan_chunk_info": (C.c_int, [_P, C.c_size_t, C.POINTER(ChunkInfo)]),
     "pqd_plan_device_ptr": (_P, [_P, C.c_size_t, C.c_int]),
@@ -93,6 +94,7 @@ SYNTH_SYMBOLS = {
     "pqw_end_row_group": (C.c_int, [_P, C.c_int64]),
     "pqw_finish": (C.c_int, [_P]),
     "pqw_data": (_P, [_P, C.POINTER(C.c_int64)]),
+    "pqw_reserve": (C.c_int, [_P, C.c_int64]),
     "pqw_encode_levels": (C.c_int64, [C.c_int, _P, C.c_int64, _P, C.c_int64]),
 }
 

@@ -78,7 +78,10 @@ struct pqd_plan {
     u32 n_ltiles = 0, n_lotiles = 0, n_stiles_chain = 0, n_btiles = 0, n_stiles = 0, n_rtiles = 0, n_copy_blocks = 0;
     int64_t bytes_in = 0, copy_bytes = 0;
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evc0 = nullptr, evc1 = nullptr;
+    // ring of per-run event sets: {run start, run end, value gather start, value gather end}
+    static constexpr int EV_RING = 256;
+    hipEvent_t ev[EV_RING][4] = {};
+    uint64_t runs = 0;
     bool ran = false, synced = false;
     int last_status = 0;
     std::vector<ChunkDyn> h_chunk_dyn;
@@ -171,10 +174,9 @@ void pqd_plan_destroy(pqd_plan* pl) {
     (void)hipStreamSynchronize(pl->ctx->stream);
     if (pl->arena) (void)hipFree(pl->arena);
     if (pl->owned_src) (void)hipFree(pl->owned_src);
-    if (pl->ev0) (void)hipEventDestroy(pl->ev0);
-    if (pl->ev1) (void)hipEventDestroy(pl->ev1);
-    if (pl->evc0) (void)hipEventDestroy(pl->evc0);
-    if (pl->evc1) (void)hipEventDestroy(pl->evc1);
+    for (auto& set : pl->ev)
+        for (hipEvent_t e : set)
+            if (e) (void)hipEventDestroy(e);
     delete pl;
 }
 
@@ -491,10 +493,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if ((rc = upload(ctx, pl->d_segs, pl->segs))) return rc;
     if ((rc = upload(ctx, pl->d_seg_blk_prefix, pl->seg_blk_prefix))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipEventCreate(&pl->ev0));
-    HIP_TRY(ctx, hipEventCreate(&pl->ev1));
-    HIP_TRY(ctx, hipEventCreate(&pl->evc0));
-    HIP_TRY(ctx, hipEventCreate(&pl->evc1));
+    for (auto& set : pl->ev)
+        for (hipEvent_t& e : set) HIP_TRY(ctx, hipEventCreate(&e));
     pl->h_chunk_dyn.resize(n_chunks);
     guard.p = nullptr;
     *out = pl;
@@ -511,15 +511,16 @@ int pqd_plan_run(pqd_plan* pl, const void* src_device) {
     const u32 n_lreg = (u32)pl->lregions.size(), n_sreg = (u32)pl->sregions.size();
     pl->last_src = src;
     pl->synced = false;
-    HIP_TRY(ctx, hipEventRecord(pl->ev0, st));
+    hipEvent_t* ev = pl->ev[pl->runs % pqd_plan::EV_RING];
+    HIP_TRY(ctx, hipEventRecord(ev[0], st));
     if (pl->ff_bytes) HIP_TRY(ctx, hipMemsetAsync(pl->ff_begin, 0xFF, pl->ff_bytes, st));
     HIP_TRY(ctx, hipMemsetAsync(pl->zero_begin, 0, pl->zero_bytes, st));
 
     // PLAIN fixed-width values: independent of the levels (the reference reads the concatenated
     // values regions as one stream)
-    HIP_TRY(ctx, hipEventRecord(pl->evc0, st));
+    HIP_TRY(ctx, hipEventRecord(ev[2], st));
     HIP_TRY(ctx, launch_copy(st, src, pl->d_segs, pl->d_seg_blk_prefix, (u32)pl->segs.size(), pl->n_copy_blocks, ctx->copy_grid));
-    HIP_TRY(ctx, hipEventRecord(pl->evc1, st));
+    HIP_TRY(ctx, hipEventRecord(ev[3], st));
 
     // levels
     if (n_lreg) {
@@ -543,7 +544,8 @@ int pqd_plan_run(pqd_plan* pl, const void* src_device) {
     }
     HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
                              pl->d_row_tiles, pl->d_chunk_dyn));
-    HIP_TRY(ctx, hipEventRecord(pl->ev1, st));
+    HIP_TRY(ctx, hipEventRecord(ev[1], st));
+    pl->runs++;
     pl->ran = true;
     return PQD_OK;
 }
@@ -567,11 +569,17 @@ int pqd_plan_sync(pqd_plan* pl) {
     return pl->last_status;
 }
 
-int pqd_plan_last_ms(pqd_plan* pl, float* total_ms, float* plain_copy_ms) {
-    if (!pl || !pl->synced) return PQD_E_ARG;
-    if (total_ms) HIP_TRY(pl->ctx, hipEventElapsedTime(total_ms, pl->ev0, pl->ev1));
-    if (plain_copy_ms) HIP_TRY(pl->ctx, hipEventElapsedTime(plain_copy_ms, pl->evc0, pl->evc1));
+int pqd_plan_run_ms(pqd_plan* pl, int runs_back, float* total_ms, float* plain_copy_ms) {
+    if (!pl || !pl->synced || runs_back < 0 || (uint64_t)runs_back >= pl->runs || runs_back >= pqd_plan::EV_RING)
+        return PQD_E_ARG;
+    hipEvent_t* ev = pl->ev[(pl->runs - 1 - (uint64_t)runs_back) % pqd_plan::EV_RING];
+    if (total_ms) HIP_TRY(pl->ctx, hipEventElapsedTime(total_ms, ev[0], ev[1]));
+    if (plain_copy_ms) HIP_TRY(pl->ctx, hipEventElapsedTime(plain_copy_ms, ev[2], ev[3]));
     return PQD_OK;
+}
+
+int pqd_plan_last_ms(pqd_plan* pl, float* total_ms, float* plain_copy_ms) {
+    return pqd_plan_run_ms(pl, 0, total_ms, plain_copy_ms);
 }
 
 int pqd_plan_chunk_info(pqd_plan* pl, size_t c, pqd_chunk_info* info) {

@@ -172,6 +172,11 @@ pqw* pqw_create(int stats_mode) {
     return w;
 }
 void pqw_destroy(pqw* w) { delete w; }
+int pqw_reserve(pqw* w, int64_t bytes) {
+    if (!w || bytes < 0) return -1;
+    w->buf.reserve((size_t)bytes);
+    return 0;
+}
 
 // rep_types[i] is the repetition (0 required, 1 optional, 2 repeated) of the i-th element of the
 // dotted path, as in the generated Field's `Types` (fields.go:163, 176-188).

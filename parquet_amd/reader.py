@@ -147,6 +147,11 @@ class Plan:
         _check(N.decode.pqd_plan_last_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def run_ms(self, runs_back):
+        a, b = C.c_float(), C.c_float()
+        _check(N.decode.pqd_plan_run_ms(self._h, runs_back, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def bytes(self):
         i, o, c = C.c_int64(), C.c_int64(), C.c_int64()
         _check(N.decode.pqd_plan_bytes(self._h, C.byref(i), C.byref(o), C.byref(c)))

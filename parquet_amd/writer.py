@@ -41,6 +41,9 @@ class ParquetWriter:
             if rc < 0:
                 raise ValueError("bad column %r" % c.path)
 
+    def reserve(self, nbytes):
+        N.synth.pqw_reserve(self._w, int(nbytes))
+
     def begin_row_group(self):
         assert N.synth.pqw_begin_row_group(self._w) == 0
         self._open = True
