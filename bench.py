@@ -43,15 +43,15 @@ def parse_args():
     return ap.parse_args()
 
 
-def build_flat_file(rank, pages, row_groups, rows_per_page):
+def build_flat_file(rg_ids, pages, rows_per_page):
     """configs[1]: three required columns, `pages` pages of `rows_per_page` rows per chunk."""
     from parquet_amd import _native as N
     from parquet_amd.writer import Column, ParquetWriter
     cols = [Column("i32", N.INT32, [0]), Column("i64", N.INT64, [0]), Column("f64", N.DOUBLE, [0])]
     w = ParquetWriter(cols, stats=True)
-    w.reserve(row_groups * pages * rows_per_page * 20 + (1 << 20))
-    rng = np.random.default_rng(1000 + rank)
-    for _ in range(row_groups):
+    w.reserve(len(rg_ids) * pages * rows_per_page * 20 + (1 << 20))
+    for g in rg_ids:
+        rng = np.random.default_rng(1000 + g)
         w.begin_row_group()
         for ci, c in enumerate(cols):
             for _ in range(pages):
@@ -68,14 +68,14 @@ def build_flat_file(rank, pages, row_groups, rows_per_page):
     return buf
 
 
-def build_optional_file(rank, pages, row_groups, rows_per_page):
+def build_optional_file(rg_ids, pages, rows_per_page):
     """configs[2]: optional int32 and string columns, 10 % nulls (def level width 1)."""
     from parquet_amd import _native as N
     from parquet_amd.writer import Column, ParquetWriter
     cols = [Column("oi32", N.INT32, [1]), Column("ostr", N.BYTE_ARRAY, [1])]
     w = ParquetWriter(cols, stats=True)
-    rng = np.random.default_rng(2000 + rank)
-    for _ in range(row_groups):
+    for g in rg_ids:
+        rng = np.random.default_rng(2000 + g)
         w.begin_row_group()
         for ci, c in enumerate(cols):
             for _ in range(pages):
@@ -96,15 +96,15 @@ def build_optional_file(rank, pages, row_groups, rows_per_page):
     return buf
 
 
-def build_nested_file(rank, pages, row_groups, rows_per_page):
+def build_nested_file(rg_ids, pages, rows_per_page):
     """configs[3]: Person{Being{id, age*}, username, Friends []Being}: rep/def levels, ragged offsets."""
     from parquet_amd import _native as N
     from parquet_amd.writer import Column, ParquetWriter
     cols = [Column("being.id", N.INT32, [0, 0]), Column("being.age", N.INT32, [0, 1]),
             Column("friends.id", N.INT32, [2, 0]), Column("friends.age", N.INT32, [2, 1])]
     w = ParquetWriter(cols, stats=True)
-    rng = np.random.default_rng(3000 + rank)
-    for _ in range(row_groups):
+    for g in rg_ids:
+        rng = np.random.default_rng(3000 + g)
         w.begin_row_group()
         for ci, c in enumerate(cols):
             for _ in range(pages):
@@ -188,7 +188,11 @@ def main():
     builders = {"flat": build_flat_file, "optional": build_optional_file, "nested": build_nested_file}
     pages = args.pages if args.workload == "flat" else min(args.pages, 8)
     t_build = time.perf_counter()
-    buf = builders[args.workload](rank, pages, args.row_groups, args.rows_per_page)
+    # The job's file has world * row_groups row groups (weak scaling); whole row groups go to ranks in
+    # contiguous ranges balanced by payload bytes, and each rank materialises only its own shard.
+    from parquet_amd import shard
+    first, count = shard.assign_row_groups([1] * (world * args.row_groups), world)[rank]
+    buf = builders[args.workload](list(range(first, first + count)), pages, args.rows_per_page)
     pf = R.ParquetFile(buf)
     t_build = time.perf_counter() - t_build
     ctx = R.Context(local_rank)

@@ -382,3 +382,28 @@ def test_full_size_pages_property(ctx):
     # and against the oracle on the optional chunk (seconds)
     o = H.oracle_file(buf)
     H.assert_chunk_equal(o[(0, "opt")], g[(0, "opt")], "opt")
+
+
+def test_reference_fixture_people(ctx):
+    """Pages of the reference's own people.parquet fixture (decompressed): GPU == oracle == pyarrow."""
+    from test_oracle_golden import _load_people, expected_people_chunk
+    buf, exp = _load_people()
+    o, g = H.check_file(buf, ctx)
+    pf = R.ParquetFile(buf)
+    rows = exp["row_group_rows"]
+    r0 = 0
+    for rg in range(2):
+        r1 = r0 + int(rows[rg])
+        for name, ci in pf.columns:
+            e = expected_people_chunk(exp, name, r0, r1)
+            got = g[(rg, name)]
+            if ci.max_def:
+                assert np.array_equal(got["defs"], e["valid"].astype(np.uint8))
+                assert np.array_equal(got["validity"], np.packbits(e["valid"], bitorder="little"))
+            if "offsets" in e:
+                assert np.array_equal(got["offsets"], e["offsets"]) and np.array_equal(got["chars"], e["chars"])
+            elif ci.phys_type == N.BOOLEAN:
+                assert np.array_equal(got["values"], e["values"].astype(np.uint8))
+            else:
+                assert got["values"].tobytes() == np.ascontiguousarray(e["values"]).tobytes()
+        r0 = r1

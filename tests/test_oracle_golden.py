@@ -181,3 +181,72 @@ def test_row_offsets_dremel_paper():
     lo, vo = O.row_offsets([1, 2, 2], [0, 0, 1], 2, 1)  # link.backward
     assert lo.tolist() == [0, 1, 3]
     assert vo.tolist() == [0, 0, 2]
+
+
+# ---------------------------------------------------------------- the reference's binary fixture
+import json
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load_people():
+    buf = open(os.path.join(GOLDEN, "people_uncompressed.parquet"), "rb").read()
+    exp = np.load(os.path.join(GOLDEN, "people_expected.npz"), allow_pickle=False)
+    return buf, exp
+
+
+def expected_people_chunk(exp, name, r0, r1):
+    """Expected arrays of one column over rows [r0, r1) from the pyarrow-decoded golden."""
+    valid = exp[name + ".valid"]
+    v0, v1 = int(valid[:r0].sum()), int(valid[:r1].sum())
+    out = {"valid": valid[r0:r1]}
+    if name + ".offsets" in exp:
+        offs = exp[name + ".offsets"]
+        out["offsets"] = (offs[v0:v1 + 1] - offs[v0]).astype(np.int32)
+        out["chars"] = exp[name + ".chars"][offs[v0]:offs[v1]]
+    else:
+        out["values"] = exp[name + ".values"][v0:v1]
+    return out
+
+
+def test_fixture_page_header_bytes():
+    # the first PageHeader of _examples/via_parquet/people.parquet, byte for byte
+    h = json.load(open(os.path.join(GOLDEN, "people_fixture_headers.json")))
+    raw = bytes.fromhex(h["first_header_hex"])
+    assert raw == bytes.fromhex("150015a00615aa062c15c8011500150615060000")
+    ph = O.page_header(raw + b"\0" * 8)
+    assert (ph.type, ph.uncompressed_page_size, ph.compressed_page_size, ph.num_values) == (0, 400, 405, 100)
+    assert (ph.encoding, ph.def_encoding, ph.rep_encoding, ph.header_len) == (0, 3, 3, 20)
+    assert h["num_pages"] == 400 and h["num_rows"] == 4000
+
+
+def test_oracle_decodes_reference_fixture_pages():
+    """Real page bytes written by the reference library (older encoder: RLE runs of length 1), expected
+    values from pyarrow reading the original snappy file."""
+    import helpers as H
+    from parquet_amd import reader as R
+    buf, exp = _load_people()
+    pf = R.ParquetFile(buf)
+    assert pf.num_rows == 4000 and pf.num_row_groups == 2 and pf.num_pages == 400
+    o = H.oracle_file(buf, pf)
+    rows = exp["row_group_rows"]
+    r0 = 0
+    for g in range(2):
+        r1 = r0 + int(rows[g])
+        for name, ci in pf.columns:
+            ch = o[(g, name)]
+            assert ch.error == 0, (g, name)
+            e = expected_people_chunk(exp, name, r0, r1)
+            if ci.max_def:
+                assert np.array_equal(ch.defs, e["valid"].astype(np.uint8)), (g, name)
+            if "offsets" in e:
+                assert np.array_equal(ch.offsets, e["offsets"]) and np.array_equal(ch.values, e["chars"]), (g, name)
+            elif ci.phys_type == 0:
+                assert np.array_equal(ch.values, e["values"].astype(np.uint8)), (g, name)
+            else:
+                assert ch.values.tobytes() == np.ascontiguousarray(e["values"]).tobytes(), (g, name)
+        r0 = r1
+    # spot values quoted from the file: row 0 = {id 0, age 20, sadness 5, keen true, anniversary 2^64-1}
+    assert o[(0, "age")].values.view(np.int32)[0] == 20
+    assert o[(0, "anniversary")].values.view(np.uint64)[0] == 18446744073709551615
