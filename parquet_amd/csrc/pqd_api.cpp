@@ -18,7 +18,7 @@ struct pqd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    u32 copy_grid = 2048;
+    u32 copy_grid = 0x7fffffffu;  // one block per 4 KiB tile; PQD_COPY_GRID caps it (then blocks grid-stride)
 };
 
 namespace {
@@ -513,7 +513,8 @@ int pqd_plan_run(pqd_plan* pl, const void* src_device) {
     pl->synced = false;
     hipEvent_t* ev = pl->ev[pl->runs % pqd_plan::EV_RING];
     HIP_TRY(ctx, hipEventRecord(ev[0], st));
-    if (pl->ff_bytes) HIP_TRY(ctx, hipMemsetAsync(pl->ff_begin, 0xFF, pl->ff_bytes, st));
+    if (pl->n_ltiles + pl->n_stiles_chain + pl->n_lotiles)
+        HIP_TRY(ctx, hipMemsetAsync(pl->ff_begin, 0xFF, pl->ff_bytes, st));
     HIP_TRY(ctx, hipMemsetAsync(pl->zero_begin, 0, pl->zero_bytes, st));
 
     // PLAIN fixed-width values: independent of the levels (the reference reads the concatenated

@@ -20,8 +20,8 @@ constexpr int PT_BOOLEAN = 0, PT_BYTE_ARRAY = 6;
 
 // ---- PLAIN value gather -------------------------------------------------------------------
 constexpr int CP_THREADS = 256;
-constexpr int CP_UNROLL = 4;
-constexpr u32 CP_BLK = CP_THREADS * 16 * CP_UNROLL;  // bytes per block iteration (16 KiB)
+constexpr int CP_UNROLL = 1;
+constexpr u32 CP_BLK = CP_THREADS * 16 * CP_UNROLL;  // bytes per block (4 KiB): many small blocks beat a grid-stride loop here
 
 struct Seg {
     u64 src_off;  // byte offset in the source buffer

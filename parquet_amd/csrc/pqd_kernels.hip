@@ -547,6 +547,7 @@ __global__ __launch_bounds__(64) void k_page_scan(const ChunkRec* __restrict__ c
         if (pi < C.n_pages) {
             page_dyn[C.first_page + pi].val_off = run_vals + sv - nn;
             page_dyn[C.first_page + pi].char_off = run_chars + sc - chars;
+            ((int64_t*)C.page_nonnull)[pi] = (int64_t)nn;  // the `sizes` slice of DoRead
         }
         run_vals += __shfl(sv, 63);
         run_chars += __shfl(sc, 63);
@@ -771,16 +772,6 @@ __global__ __launch_bounds__(64) void k_rows_scan(const ChunkRec* __restrict__ c
     }
 }
 
-// Per-page non-null counts as int64 (the `sizes` slice of DoRead).
-__global__ void k_page_sizes(const ChunkRec* __restrict__ chunks, const PageRec* __restrict__ pages, u32 n_pages,
-                             const PageDyn* __restrict__ page_dyn) {
-    const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pages) return;
-    const PageRec P = pages[p];
-    const ChunkRec C = chunks[P.chunk];
-    ((int64_t*)C.page_nonnull)[p - C.first_page] = C.max_def > 0 ? (int64_t)page_dyn[p].nn : (int64_t)P.num_values;
-}
-
 // =====================================================================================
 // launch wrappers (called from pqd_api.cpp)
 // =====================================================================================
@@ -851,8 +842,6 @@ hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks
                             PageDyn* page_dyn, ChunkDyn* chunk_dyn, int* status) {
     if (n_chunks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_page_scan, dim3(n_chunks), dim3(64), 0, st, chunks, n_chunks, pages, page_dyn, chunk_dyn, status);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_page_sizes, dim3((n_pages + 255) / 256), dim3(256), 0, st, chunks, pages, n_pages, page_dyn);
     LAUNCH_CHECK();
     return hipSuccess;
 }
