@@ -31,11 +31,12 @@ struct Seg {
 
 // ---- chain resolution (run headers, BYTE_ARRAY lengths) ---------------------------------------
 constexpr int KIND_LEVELS = 0, KIND_STRINGS = 1;
-constexpr u32 CH_T = 2048;        // source bytes per tile
-constexpr u32 CH_THREADS = 256;
-constexpr u32 CH_PPT = CH_T / CH_THREADS;
-constexpr u32 CH_HALO = 16;
-constexpr u32 CH_E_LEVELS = 512;  // tabulated entry positions per tile: covers a 64-group run at width <= 7
+constexpr u32 CH_SUB = 32;        // source bytes per lane (sub-tile)
+constexpr u32 CH_THREADS = 64;    // one wavefront per tile
+constexpr u32 CH_T = CH_THREADS * CH_SUB;  // source bytes per tile (2048)
+constexpr u32 CH_WIN = CH_SUB / 4 + 2;    // dwords a lane holds: its sub-tile + 8 bytes of lookahead
+constexpr u32 CH_E_LEVELS = 256;  // tabulated entry positions per tile: covers the reference writer's longest
+                                  // run (1 + 63 groups x 4 bytes); longer jumps take the serial hop
 constexpr u32 CH_E_STRINGS = 64;  // covers values up to 60 bytes; longer ones take the serial hop
 
 constexpr u32 OT = 4096;          // level values per expand tile

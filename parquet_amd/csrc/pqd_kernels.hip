@@ -91,48 +91,54 @@ __global__ __launch_bounds__(CP_THREADS) void k_copy(const u8* __restrict__ src_
 // =====================================================================================
 // Chain resolution.  Both run headers of a hybrid-RLE block and PLAIN BYTE_ARRAY values form a
 // chain: the position of element k+1 is only known after decoding element k.  Three kernels turn
-// the chain into parallel work:
-//   k_chain<.., false>   per CH_T-byte tile: treat EVERY byte as a possible element start, compute its
-//                        successor, then pointer-double inside LDS until every start knows where its
-//                        chain leaves the tile (and how many elements / level values it passes).
-//                        The first E starts of each tile are written to an exit table.
-//   k_chain_resolve      one thread per region hops tile to tile through the exit table and records
-//                        where the true chain enters each tile.
-//   k_chain<.., true>    per tile again, now marking the true chain while doubling
-//                        (marked ∪ jump_2^k(marked) doubles the marked prefix each round), then emits
-//                        one record per true element.
+// the chain into parallel work.  A tile is CH_T = 64 x CH_SUB source bytes and belongs to one
+// wavefront; lane l owns the CH_SUB-byte sub-tile l.
+//   k_chain<.., false>   Treats EVERY byte as a possible element start.  Each lane sweeps its
+//                        sub-tile backwards once: the successor of a start either leaves the sub-tile
+//                        or lands on a later start of the same sub-tile whose answer is already
+//                        memoised, so every start learns in O(1) where its chain leaves the sub-tile
+//                        and how many elements / level values it passes.  A second backward sweep over
+//                        the 64 sub-tiles turns these into tile exits.  The first E starts of each
+//                        tile go to an exit table.
+//   k_chain_resolve      hops from tile to tile through the exit table and records where the true
+//                        chain enters each tile.
+//   k_chain<.., true>    same per-lane sweep; lane 0 then follows the true chain from sub-tile to
+//                        sub-tile (<= 64 hops), and every lane walks its sub-tile from its true entry,
+//                        emitting one record per true element.
+// Each lane keeps its sub-tile bytes in registers (the sweeps are fully unrolled, so every header is
+// parsed with constant funnel shifts); the memo tables live in LDS at index offset*65 + lane, so lanes
+// working on the same offset of different sub-tiles hit different banks.
 // =====================================================================================
 
 struct GlobalBytes {
     const u8* p;
     __device__ __forceinline__ u32 operator()(u32 q) const { return p[q]; }
 };
-struct LdsBytes {
-    const u8* p;  // LDS copy of the tile
-    u32 base;     // region position of p[0]
-    __device__ __forceinline__ u32 operator()(u32 q) const { return p[q - base]; }
-};
+static __device__ __forceinline__ u32 sat_add32(u32 a, u32 b) {
+    const u32 s = a + b;
+    return s < a ? 0xFFFFFFFFu : s;
+}
+static __device__ __forceinline__ u32 memo_idx(u32 rel) { return (rel % CH_SUB) * 65 + rel / CH_SUB; }
 
-// One hybrid-RLE run header at region position p (p < L).  nxt = position of the next header
-// (== L when the block ends), ERR_POS when the reference would fail:
-//   header even → RLE run: count = header >> 1, value in ceil(w/8) bytes (rle.go:218-244)
-//   header odd  → bit-packed: groups = header >> 1, values = 8*groups, w*groups bytes; a short read is
-//                 zero padded, a read at the very end of the block is io.EOF (rle.go:197-216)
+// One hybrid-RLE run header at region position p (p < L), given x = the 8 bytes at p..p+7 (bytes at or
+// past L read as zero).  nxt = position of the next header (== L when the block ends), ERR_POS when the
+// reference would fail:
+//   header = ULEB128 (readLEB128, rle.go:274-290; headers longer than 8 bytes are rejected here)
+//   even → RLE run: count = header >> 1, value in ceil(w/8) bytes (rle.go:218-244)
+//   odd  → bit-packed: groups = header >> 1, values = 8*groups, w*groups bytes; a short read is zero
+//          padded, a read at the very end of the block is io.EOF (rle.go:197-216)
 // info = (position of the value byte(s) or of the packed bytes) << 1 | bit-packed flag.
-template <class Bytes>
-static __device__ __forceinline__ void rle_step(const Bytes& B, u32 p, u32 L, u32 w, u32& nxt, u64& vals, u32& info) {
-    u64 h = 0;
-    u32 q = p, shift = 0;
-    bool ok = false;
-    for (int k = 0; k < 10; k++) {
-        if (q >= L) break;
-        const u32 b = B(q++);
-        h |= (u64)(b & 0x7F) << shift;
-        shift += 7;
-        if (!(b & 0x80)) { ok = true; break; }
-    }
+static __device__ __forceinline__ void rle_step_win(u64 x, u32 p, u32 L, u32 w, u32& nxt, u64& vals, u32& info) {
     nxt = ERR_POS; vals = 0; info = 0;
-    if (!ok) return;
+    const u64 stop = ~x & 0x8080808080808080ull;
+    if (!stop) return;
+    const u32 n = ((u32)__builtin_ctzll(stop) >> 3) + 1;  // header bytes
+    if (n > L - p) return;                                // header cut off by the end of the block
+    const u64 y = x & (0x7F7F7F7F7F7F7F7Full >> (8 * (8 - n)));
+    const u64 h = (y & 0x7F) | ((y >> 1) & (0x7Full << 7)) | ((y >> 2) & (0x7Full << 14)) | ((y >> 3) & (0x7Full << 21)) |
+                  ((y >> 4) & (0x7Full << 28)) | ((y >> 5) & (0x7Full << 35)) | ((y >> 6) & (0x7Full << 42)) |
+                  ((y >> 7) & (0x7Full << 49));
+    const u32 q = p + n;
     if ((h & 1) == 0) {
         const u64 count = h >> 1;
         if (count > (1ull << 31)) return;
@@ -144,27 +150,56 @@ static __device__ __forceinline__ void rle_step(const Bytes& B, u32 p, u32 L, u3
     } else {
         const u64 groups = h >> 1;
         if (groups > (1ull << 28)) return;
-        vals = groups * 8;
         info = (q << 1) | 1;
-        if (w == 0) { nxt = q; return; }
-        if (q >= L) { vals = 0; return; }  // exhausted reader: io.EOF
+        if (w == 0) { vals = groups * 8; nxt = q; return; }
+        if (q >= L) return;           // exhausted reader: io.EOF
+        vals = groups * 8;
         const u64 e = (u64)q + (u64)w * groups;
         nxt = e > L ? L : (u32)e;
     }
 }
 
-// One PLAIN BYTE_ARRAY value at region position p: int32 LE length, then the bytes
-// (template_string.go:47-58).  A negative length panics in the reference; a value running past the
-// region is reported as corrupt.
-template <class Bytes>
-static __device__ __forceinline__ void str_step(const Bytes& B, u32 p, u32 L, u32& nxt) {
+// One PLAIN BYTE_ARRAY value at region position p given its 4 length bytes: int32 LE length, then the
+// bytes (template_string.go:47-58).  A negative length panics in the reference; a value running past
+// the region is reported as corrupt.
+static __device__ __forceinline__ void str_step_win(u32 len, u32 p, u32 L, u32& nxt) {
     nxt = ERR_POS;
     if (L - p < 4) return;
-    const u32 len = B(p) | (B(p + 1) << 8) | (B(p + 2) << 16) | (B(p + 3) << 24);
     if (len & 0x80000000u) return;
     const u64 e = (u64)p + 4 + len;
     if (e > L) return;
     nxt = (u32)e;
+}
+
+// The same steps reading their bytes one at a time (used off the fast path).
+template <class Bytes>
+static __device__ __forceinline__ void rle_step(const Bytes& B, u32 p, u32 L, u32 w, u32& nxt, u64& vals, u32& info) {
+    u64 x = 0;
+    for (u32 k = 0; k < 8 && p + k < L; k++) {
+        const u64 b = B(p + k);
+        x |= b << (8 * k);
+        if (!(b & 0x80)) break;
+    }
+    rle_step_win(x, p, L, w, nxt, vals, info);
+}
+template <class Bytes>
+static __device__ __forceinline__ void str_step(const Bytes& B, u32 p, u32 L, u32& nxt) {
+    u32 len = 0;
+    if (L - p >= 4) len = B(p) | (B(p + 1) << 8) | (B(p + 2) << 16) | (B(p + 3) << 24);
+    str_step_win(len, p, L, nxt);
+}
+
+// Bytes k..k+7 / k..k+3 of a lane's register image w[] (its sub-tile plus 8 bytes of lookahead); k is a
+// compile-time constant after unrolling, so these are plain register funnel shifts.
+static __device__ __forceinline__ u64 win64(const u32 (&w)[CH_WIN], int k) {
+    const int d = k >> 2, sh = (k & 3) * 8;
+    const u32 lo = sh ? (w[d] >> sh) | (w[d + 1] << (32 - sh)) : w[d];
+    const u32 hi = sh ? (w[d + 1] >> sh) | (w[d + 2] << (32 - sh)) : w[d + 1];
+    return lo | ((u64)hi << 32);
+}
+static __device__ __forceinline__ u32 win32(const u32 (&w)[CH_WIN], int k) {
+    const int d = k >> 2, sh = (k & 3) * 8;
+    return sh ? (w[d] >> sh) | (w[d + 1] << (32 - sh)) : w[d];
 }
 
 template <int KIND, bool MARK>
@@ -174,13 +209,14 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
                                                       RunRec* __restrict__ run_tbl, u32* __restrict__ otile_first_run,
                                                       const PageDyn* __restrict__ page_dyn) {
     constexpr u32 E = KIND == KIND_LEVELS ? CH_E_LEVELS : CH_E_STRINGS;
-    __shared__ u32 s_tgt[2][CH_T];
-    __shared__ unsigned short s_cnt[2][CH_T];
-    __shared__ u64 s_acc[KIND == KIND_LEVELS ? 2 : 1][KIND == KIND_LEVELS ? CH_T : 1];
-    __shared__ __attribute__((aligned(16))) u8 s_b[CH_T + CH_HALO];
-    __shared__ u8 s_mark[MARK ? CH_T : 1];
+    constexpr u32 MEMO = CH_SUB * 65;
+    __shared__ u32 m_tgt[MEMO];
+    __shared__ unsigned short m_cnt[MEMO];
+    __shared__ u32 m_val[KIND == KIND_LEVELS ? MEMO : 1];
+    __shared__ u32 e_pos[MARK ? 64 : 1], e_cnt[MARK ? 64 : 1];
+    __shared__ u64 e_val[MARK ? 64 : 1];
 
-    const u32 tid = threadIdx.x;
+    const u32 lane = threadIdx.x;
     const u32 tile = blockIdx.x;
     const u32 ri = find_owner(tile_prefix, n_regions, tile);
     const Region R = regions[ri];
@@ -193,108 +229,145 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
     if (MARK) {
         ent = tile_entry[tile];
         if (ent.pos == ERR_POS) return;  // the true chain never starts an element in this tile
+        e_pos[lane] = ERR_POS;
     }
 
-    // stage the tile (+ halo for headers that straddle the tile end) in LDS; bytes past L read as 0
-    for (u32 i = tid * 8; i < CH_T + CH_HALO; i += CH_THREADS * 8) {
-        const u32 p = tb + i;
-        u64 v = 0;
+    // my sub-tile and 8 bytes of lookahead, in registers; bytes at or past L read as 0
+    const u32 sub_lo = tb + lane * CH_SUB, sub_hi = sub_lo + CH_SUB;
+    u32 w[CH_WIN];
+#pragma unroll
+    for (int d = 0; d < (int)CH_WIN; d++) {
+        const u32 p = sub_lo + 4 * d;
+        u32 v = 0;
         if (p < L) {
-            if (L - p >= 8) v = *(const u64_u*)(rsrc + p);
-            else for (u32 k = 0; k < L - p; k++) v |= (u64)rsrc[p + k] << (8 * k);
+            if (L - p >= 4) v = *(const u32_u*)(rsrc + p);
+            else for (u32 k = 0; k < L - p; k++) v |= (u32)rsrc[p + k] << (8 * k);
         }
-        *(u64*)(s_b + i) = v;
+        w[d] = v;
     }
-    if (MARK) for (u32 i = tid; i < CH_T; i += CH_THREADS) s_mark[i] = 0;
-    __syncthreads();
 
-    const LdsBytes B{s_b, tb};
-    for (u32 k = 0; k < CH_PPT; k++) {
-        const u32 i = tid + k * CH_THREADS;
-        const u32 p = tb + i;
-        u32 nxt = p;
-        u64 vals = 0;
-        unsigned short c = 0;
+    // ---- sweep 1: every start of my sub-tile learns where its chain leaves the sub-tile
+#pragma unroll
+    for (int k = CH_SUB - 1; k >= 0; k--) {
+        const u32 p = sub_lo + k;
+        u32 tgt = p, c = 0, v = 0;
         if (p < L) {
-            c = 1;
-            if (KIND == KIND_LEVELS) { u32 info; rle_step(B, p, L, R.width, nxt, vals, info); }
-            else str_step(B, p, L, nxt);
-        }
-        s_tgt[0][i] = nxt;
-        s_cnt[0][i] = c;
-        if (KIND == KIND_LEVELS) s_acc[0][i] = vals;
-    }
-    if (MARK && tid == 0) s_mark[ent.pos - tb] = 1;
-    __syncthreads();
-
-    int cur = 0;
-    for (int round = 0; round < 12; round++) {
-        int changed = 0;
-        for (u32 k = 0; k < CH_PPT; k++) {
-            const u32 i = tid + k * CH_THREADS;
-            u32 t = s_tgt[cur][i];
-            unsigned short c = s_cnt[cur][i];
-            u64 a = 0;
-            if (KIND == KIND_LEVELS) a = s_acc[cur][i];
-            if (t < te && t < L && tb + i < L) {
-                const u32 j = t - tb;
-                if (MARK && s_mark[i]) s_mark[j] = 1;
-                t = s_tgt[cur][j];
-                c = (unsigned short)(c + s_cnt[cur][j]);
-                if (KIND == KIND_LEVELS) a += s_acc[cur][j];
-                changed = 1;
+            u32 nxt;
+            u64 vals = 0;
+            if (KIND == KIND_LEVELS) { u32 info; rle_step_win(win64(w, k), p, L, R.width, nxt, vals, info); }
+            else str_step_win(win32(w, k), p, L, nxt);
+            tgt = nxt; c = 1; v = (u32)vals;  // one run never holds more than 2^31 values
+            if (nxt < sub_hi && nxt < L) {     // lands on a later start of this sub-tile: memoised
+                const u32 mi = memo_idx(nxt - tb);
+                tgt = m_tgt[mi];
+                c += m_cnt[mi];
+                if (KIND == KIND_LEVELS) v = sat_add32(v, m_val[mi]);
             }
-            s_tgt[cur ^ 1][i] = t;
-            s_cnt[cur ^ 1][i] = c;
-            if (KIND == KIND_LEVELS) s_acc[cur ^ 1][i] = a;
         }
-        cur ^= 1;
-        if (!__syncthreads_or(changed)) break;
+        const u32 mi = memo_idx(p - tb);
+        m_tgt[mi] = tgt;
+        m_cnt[mi] = (unsigned short)c;
+        if (KIND == KIND_LEVELS) m_val[mi] = v;
     }
+    __syncthreads();
 
     if (!MARK) {
+        // ---- sweep 2: sub-tile exits -> tile exits, in two levels of 8 (groups of 8 sub-tiles = 256 bytes).
+        // A start whose chain lands on a later start takes over that start's already final answer.
+        // Level A: inside every group, sub-tiles from last to first (all 8 groups at once, 4 starts per lane).
+        for (int j = 6; j >= 0; j--) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u32 g = 2 * i + (lane >> 5), k = lane & 31;
+                const u32 rel = (g * 8 + (u32)j) * CH_SUB + k;
+                const u32 mi = memo_idx(rel);
+                const u32 t = m_tgt[mi];
+                if (tb + rel < L && t < tb + (g + 1) * 8 * CH_SUB && t < L) {
+                    const u32 mj = memo_idx(t - tb);
+                    m_tgt[mi] = m_tgt[mj];
+                    m_cnt[mi] = (unsigned short)(m_cnt[mi] + m_cnt[mj]);
+                    if (KIND == KIND_LEVELS) m_val[mi] = sat_add32(m_val[mi], m_val[mj]);
+                }
+            }
+            __syncthreads();
+        }
+        // Level B: groups from last to first (256 starts per stage, 4 per lane).
+        for (int g = 6; g >= 0; g--) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u32 rel = (u32)g * 8 * CH_SUB + (2 * i + (lane >> 5)) * CH_SUB + (lane & 31);
+                const u32 mi = memo_idx(rel);
+                const u32 t = m_tgt[mi];
+                if (tb + rel < L && t < te && t < L) {
+                    const u32 mj = memo_idx(t - tb);
+                    m_tgt[mi] = m_tgt[mj];
+                    m_cnt[mi] = (unsigned short)(m_cnt[mi] + m_cnt[mj]);
+                    if (KIND == KIND_LEVELS) m_val[mi] = sat_add32(m_val[mi], m_val[mj]);
+                }
+            }
+            __syncthreads();
+        }
         // exit table: where the chain started at each of the first E positions leaves the tile
-        for (u32 i = tid; i < E; i += CH_THREADS) {
+        for (u32 i = lane; i < E; i += 64) {
+            const u32 mi = memo_idx(i);
             ExitRec x;
-            x.tgt = s_tgt[cur][i];
-            x.cnt = s_cnt[cur][i];
-            x.vals = KIND == KIND_LEVELS ? s_acc[cur][i] : 0;
+            x.tgt = m_tgt[mi];
+            x.cnt = m_cnt[mi];
+            x.vals = KIND == KIND_LEVELS ? m_val[mi] : 0;
             exit_tbl[(u64)tile * E + i] = x;
         }
         return;
     }
 
-    // ---- MARK: one record per element of the true chain that starts in this tile
-    const u32 e_i = ent.pos - tb;
-    const u32 K = s_cnt[cur][e_i];
-    for (u32 k = 0; k < CH_PPT; k++) {
-        const u32 i = tid + k * CH_THREADS;
-        if (!s_mark[i]) continue;
-        const u32 p = tb + i;
-        const u32 rank = ent.cnt + (K - s_cnt[cur][i]);  // index of this element within the region
-        if (KIND == KIND_LEVELS) {
-            u32 nxt, info;
-            u64 vals;
-            rle_step(B, p, L, R.width, nxt, vals, info);
-            const u64 o = ent.vals + (s_acc[cur][e_i] - s_acc[cur][i]);  // first level value of the run
-            const u64 n_out = R.n_out;
-            RunRec rr;
-            rr.out_off = o < n_out ? (u32)o : (u32)n_out;
-            rr.info = info;
-            run_tbl[R.run_base + rank] = rr;
-            // which output tiles start inside this run
-            if (vals > 0 && o < n_out) {
-                u64 oe = o + vals < n_out ? o + vals : n_out;
-                for (u64 t = (o + OT - 1) / OT; t * OT < oe; t++) otile_first_run[R.otile_base + t] = rank;
+    // ---- MARK: lane 0 follows the true chain from sub-tile to sub-tile
+    if (lane == 0) {
+        u32 q = ent.pos, c = ent.cnt;
+        u64 v = ent.vals;
+        while (q < te && q < L) {
+            const u32 rel = q - tb, sidx = rel / CH_SUB, mi = memo_idx(rel);
+            e_pos[sidx] = q; e_cnt[sidx] = c; e_val[sidx] = v;
+            c += m_cnt[mi];
+            if (KIND == KIND_LEVELS) v += m_val[mi];
+            q = m_tgt[mi];
+        }
+    }
+    __syncthreads();
+    // ---- every lane replays its sub-tile from its true entry: one record per true element
+    u32 q = e_pos[lane];
+    if (q == ERR_POS) return;
+    u32 rank = e_cnt[lane];  // index of the element within the region
+    u64 o = e_val[lane];     // levels: index of the run's first level value
+    const u64 n_out = R.n_out;
+#pragma unroll
+    for (int k = 0; k < (int)CH_SUB; k++) {
+        if (q == sub_lo + k && q < L) {
+            u32 nxt;
+            if (KIND == KIND_LEVELS) {
+                u32 info;
+                u64 vals;
+                rle_step_win(win64(w, k), q, L, R.width, nxt, vals, info);
+                RunRec rr;
+                rr.out_off = o < n_out ? (u32)o : (u32)n_out;
+                rr.info = info;
+                run_tbl[R.run_base + rank] = rr;
+                // which output tiles start inside this run
+                if (vals > 0 && o < n_out) {
+                    const u64 oe = o + vals < n_out ? o + vals : n_out;
+                    for (u64 t = (o + OT - 1) / OT; t * OT < oe; t++) otile_first_run[R.otile_base + t] = rank;
+                }
+                o += vals;
+            } else {
+                str_step_win(win32(w, k), q, L, nxt);
+                // string `rank` of the page starts at q: its chars begin at q + 4; every earlier string of
+                // the page contributed 4 length bytes.  A page never holds more values than levels.
+                if (rank < n_out) {
+                    const PageDyn pd = page_dyn[R.page];
+                    int32_t* offsets = (int32_t*)R.out;
+                    offsets[pd.val_off + rank] = (int32_t)(pd.char_off + (u64)q - 4ull * rank);
+                }
             }
-        } else {
-            // string `rank` of the page starts at p: its chars begin at p + 4; every earlier string
-            // of the page contributed 4 length bytes
-            if (rank < R.n_out) {  // a page can never hold more values than levels
-                const PageDyn pd = page_dyn[R.page];
-                int32_t* offsets = (int32_t*)R.out;
-                offsets[pd.val_off + rank] = (int32_t)(pd.char_off + (u64)p - 4ull * rank);
-            }
+            rank++;
+            q = nxt;
         }
     }
 }
