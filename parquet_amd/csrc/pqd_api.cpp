@@ -50,7 +50,7 @@ struct pqd_plan {
     std::vector<ChunkRec> chunks;
     std::vector<PageRec> pages;
     std::vector<Region> lregions, sregions;
-    std::vector<u32> ltile_prefix, lotile_prefix, stile_chain_prefix;
+    std::vector<u32> ltile_prefix, lotile_prefix, stile_chain_prefix, lgroup_prefix, sgroup_prefix;
     std::vector<Seg> segs;
     std::vector<u32> seg_blk_prefix;
     std::vector<u32> bool_pages, btile_prefix, str_pages, stile_prefix, row_chunks, rtile_prefix;
@@ -63,11 +63,13 @@ struct pqd_plan {
     ChunkRec* d_chunks = nullptr; PageRec* d_pages = nullptr;
     Region *d_lregions = nullptr, *d_sregions = nullptr;
     u32 *d_ltile_prefix = nullptr, *d_lotile_prefix = nullptr, *d_stile_chain_prefix = nullptr;
+    u32 *d_lgroup_prefix = nullptr, *d_sgroup_prefix = nullptr;
     Seg* d_segs = nullptr; u32* d_seg_blk_prefix = nullptr;
     u32 *d_bool_pages = nullptr, *d_btile_prefix = nullptr, *d_str_pages = nullptr, *d_stile_prefix = nullptr;
     u32 *d_row_chunks = nullptr, *d_rtile_prefix = nullptr;
-    ExitRec *d_lexit = nullptr, *d_sexit = nullptr;
-    TileEntry *d_ltile_entry = nullptr, *d_stile_entry = nullptr;
+    ExitRec *d_lexit = nullptr, *d_sexit = nullptr, *d_lgexit = nullptr, *d_sgexit = nullptr;
+    TileEntry *d_ltile_entry = nullptr, *d_stile_entry = nullptr, *d_lgroup_entry = nullptr, *d_sgroup_entry = nullptr;
+    ChainArgs lchain = {}, schain = {};
     RegionTotal *d_ltotals = nullptr, *d_stotals = nullptr;
     RunRec* d_runs = nullptr; u32* d_otile_first = nullptr;
     PageDyn* d_page_dyn = nullptr; ChunkDyn* d_chunk_dyn = nullptr; RowTile* d_row_tiles = nullptr;
@@ -304,6 +306,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->ltile_prefix.push_back(0);
     pl->lotile_prefix.push_back(0);
     pl->stile_chain_prefix.push_back(0);
+    pl->lgroup_prefix.push_back(0);
+    pl->sgroup_prefix.push_back(0);
     pl->btile_prefix.push_back(0);
     pl->stile_prefix.push_back(0);
     pl->rtile_prefix.push_back(0);
@@ -329,6 +333,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                 R.len = nb - 4;
                 R.width = (u32)bits_len((unsigned)(lv == 0 ? C.max_rep : C.max_def));
                 R.tile_base = pl->ltile_prefix.back();
+                R.group_base = pl->lgroup_prefix.back();
                 R.otile_base = pl->lotile_prefix.back();
                 R.run_base = run_base;
                 R.n_out = P.num_values;
@@ -337,6 +342,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                 R.count_level = lv == 1 ? (u32)C.max_def : ERR_POS;
                 pl->lregions.push_back(R);
                 push_prefix(pl->ltile_prefix, (R.len + CH_T - 1) / CH_T, ovf);
+                push_prefix(pl->lgroup_prefix, ((u64)R.len + CH_G_LEVELS * CH_T - 1) / (CH_G_LEVELS * CH_T), ovf);
                 push_prefix(pl->lotile_prefix, ((u64)P.num_values + OT - 1) / OT, ovf);
                 run_base += R.len;
                 l += nb;
@@ -347,11 +353,13 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                 R.src_off = P.val_src_off;
                 R.len = P.val_len;
                 R.tile_base = pl->stile_chain_prefix.back();
+                R.group_base = pl->sgroup_prefix.back();
                 R.n_out = P.num_values;
                 R.page = pi;
                 R.count_level = ERR_POS;
                 pl->sregions.push_back(R);
                 push_prefix(pl->stile_chain_prefix, ((u64)P.val_len + CH_T - 1) / CH_T, ovf);
+                push_prefix(pl->sgroup_prefix, ((u64)P.val_len + CH_G_STRINGS * CH_T - 1) / (CH_G_STRINGS * CH_T), ovf);
                 pl->str_pages.push_back(pi);
                 push_prefix(pl->stile_prefix, ((u64)P.val_len + ST - 1) / ST, ovf);
             } else if (C.phys_type == PQD_BOOLEAN) {
@@ -380,6 +388,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_ltp = ap.take(pl->ltile_prefix.size() * 4);
     const size_t o_lotp = ap.take(pl->lotile_prefix.size() * 4);
     const size_t o_sctp = ap.take(pl->stile_chain_prefix.size() * 4);
+    const size_t o_lgp = ap.take(pl->lgroup_prefix.size() * 4);
+    const size_t o_sgp = ap.take(pl->sgroup_prefix.size() * 4);
     const size_t o_bp = ap.take(pl->bool_pages.size() * 4);
     const size_t o_btp = ap.take(pl->btile_prefix.size() * 4);
     const size_t o_sp = ap.take(pl->str_pages.size() * 4);
@@ -389,6 +399,9 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     // scratch
     const size_t o_lexit = ap.take((size_t)pl->n_ltiles * CH_E_LEVELS * sizeof(ExitRec));
     const size_t o_sexit = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * sizeof(ExitRec));
+    const u32 n_lgroups = pl->lgroup_prefix.back(), n_sgroups = pl->sgroup_prefix.back();
+    const size_t o_lgexit = ap.take((size_t)n_lgroups * CH_E_LEVELS * sizeof(ExitRec));
+    const size_t o_sgexit = ap.take((size_t)n_sgroups * CH_E_STRINGS * sizeof(ExitRec));
     const size_t o_ltot = ap.take(pl->lregions.size() * sizeof(RegionTotal));
     const size_t o_stot = ap.take(pl->sregions.size() * sizeof(RegionTotal));
     const size_t o_runs = ap.take((size_t)run_base * sizeof(RunRec));
@@ -398,6 +411,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_ff = ap.total;
     const size_t o_lte = ap.take((size_t)pl->n_ltiles * sizeof(TileEntry));
     const size_t o_ste = ap.take((size_t)pl->n_stiles_chain * sizeof(TileEntry));
+    const size_t o_lge = ap.take((size_t)n_lgroups * sizeof(TileEntry));
+    const size_t o_sge = ap.take((size_t)n_sgroups * sizeof(TileEntry));
     const size_t o_otf = ap.take((size_t)pl->n_lotiles * 4);
     const size_t ff_end = ap.total;
     // reset to 0 every run
@@ -462,6 +477,9 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->d_lregions = (Region*)(A + o_lreg); pl->d_sregions = (Region*)(A + o_sreg);
     pl->d_ltile_prefix = (u32*)(A + o_ltp); pl->d_lotile_prefix = (u32*)(A + o_lotp);
     pl->d_stile_chain_prefix = (u32*)(A + o_sctp);
+    pl->d_lgroup_prefix = (u32*)(A + o_lgp); pl->d_sgroup_prefix = (u32*)(A + o_sgp);
+    pl->d_lgexit = (ExitRec*)(A + o_lgexit); pl->d_sgexit = (ExitRec*)(A + o_sgexit);
+    pl->d_lgroup_entry = (TileEntry*)(A + o_lge); pl->d_sgroup_entry = (TileEntry*)(A + o_sge);
     pl->d_bool_pages = (u32*)(A + o_bp); pl->d_btile_prefix = (u32*)(A + o_btp);
     pl->d_str_pages = (u32*)(A + o_sp); pl->d_stile_prefix = (u32*)(A + o_stp);
     pl->d_row_chunks = (u32*)(A + o_rc); pl->d_rtile_prefix = (u32*)(A + o_rtp);
@@ -476,6 +494,11 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->ff_begin = A + o_ff; pl->ff_bytes = ff_end - o_ff;
     pl->zero_begin = A + o_zero; pl->zero_bytes = zero_end - o_zero;
 
+    pl->lchain = ChainArgs{pl->d_lregions, pl->d_ltile_prefix, pl->d_lgroup_prefix, (u32)pl->lregions.size(), pl->n_ltiles, n_lgroups,
+                           pl->d_lexit, pl->d_lgexit, pl->d_ltile_entry, pl->d_lgroup_entry, pl->d_ltotals};
+    pl->schain = ChainArgs{pl->d_sregions, pl->d_stile_chain_prefix, pl->d_sgroup_prefix, (u32)pl->sregions.size(), pl->n_stiles_chain,
+                           n_sgroups, pl->d_sexit, pl->d_sgexit, pl->d_stile_entry, pl->d_sgroup_entry, pl->d_stotals};
+
     int rc;
     if ((rc = upload(ctx, pl->d_chunks, pl->chunks))) return rc;
     if ((rc = upload(ctx, pl->d_pages, pl->pages))) return rc;
@@ -484,6 +507,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if ((rc = upload(ctx, pl->d_ltile_prefix, pl->ltile_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_lotile_prefix, pl->lotile_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_stile_chain_prefix, pl->stile_chain_prefix))) return rc;
+    if ((rc = upload(ctx, pl->d_lgroup_prefix, pl->lgroup_prefix))) return rc;
+    if ((rc = upload(ctx, pl->d_sgroup_prefix, pl->sgroup_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_bool_pages, pl->bool_pages))) return rc;
     if ((rc = upload(ctx, pl->d_btile_prefix, pl->btile_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_str_pages, pl->str_pages))) return rc;
@@ -525,10 +550,8 @@ int pqd_plan_run(pqd_plan* pl, const void* src_device) {
 
     // levels
     if (n_lreg) {
-        HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, src, pl->d_lregions, pl->d_ltile_prefix, n_lreg, pl->n_ltiles, pl->d_lexit,
-                                  pl->d_ltile_entry, pl->d_ltotals, pl->d_runs, pl->d_otile_first, pl->d_page_dyn, pl->d_status, 0));
-        HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, src, pl->d_lregions, pl->d_ltile_prefix, n_lreg, pl->n_ltiles, pl->d_lexit,
-                                  pl->d_ltile_entry, pl->d_ltotals, pl->d_runs, pl->d_otile_first, pl->d_page_dyn, pl->d_status, 1));
+        HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, src, pl->lchain, pl->d_runs, pl->d_otile_first, pl->d_page_dyn, pl->d_status, 0));
+        HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, src, pl->lchain, pl->d_runs, pl->d_otile_first, pl->d_page_dyn, pl->d_status, 1));
         HIP_TRY(ctx, launch_levels_expand(st, 1, src, pl->d_lregions, pl->d_lotile_prefix, n_lreg, pl->n_lotiles, pl->d_runs,
                                           pl->d_otile_first, pl->d_ltotals, pl->d_page_dyn));
     }
@@ -536,10 +559,8 @@ int pqd_plan_run(pqd_plan* pl, const void* src_device) {
     HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, (u32)pl->bool_pages.size(), pl->n_btiles,
                               pl->d_chunks, pl->d_page_dyn));
     if (n_sreg) {
-        HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->d_sregions, pl->d_stile_chain_prefix, n_sreg, pl->n_stiles_chain,
-                                  pl->d_sexit, pl->d_stile_entry, pl->d_stotals, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 0));
-        HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->d_sregions, pl->d_stile_chain_prefix, n_sreg, pl->n_stiles_chain,
-                                  pl->d_sexit, pl->d_stile_entry, pl->d_stotals, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 1));
+        HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 0));
+        HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 1));
         HIP_TRY(ctx, launch_str_gather(st, src, pl->d_pages, pl->d_str_pages, pl->d_stile_prefix, (u32)pl->str_pages.size(),
                                        pl->n_stiles, pl->d_chunks, pl->d_page_dyn, pl->d_sregions, n_sreg, pl->d_stotals, pl->d_status));
     }
@@ -681,16 +702,19 @@ int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block_, size_t block_len
     hipStream_t st = ctx->stream;
     const u32 n_tiles = ((u32)len + CH_T - 1) / CH_T;
     const u32 n_otiles = (u32)((max_values + OT - 1) / OT);
+    const u32 n_groups = (n_tiles + CH_G_LEVELS - 1) / CH_G_LEVELS;
     ArenaPlan ap;
     const size_t o_src = ap.take((size_t)len + 64);
     const size_t o_reg = ap.take(sizeof(Region));
-    const size_t o_tp = ap.take(8), o_otp = ap.take(8);
+    const size_t o_tp = ap.take(8), o_otp = ap.take(8), o_gp = ap.take(8);
     const size_t o_exit = ap.take((size_t)n_tiles * CH_E_LEVELS * sizeof(ExitRec));
+    const size_t o_gexit = ap.take((size_t)n_groups * CH_E_LEVELS * sizeof(ExitRec));
     const size_t o_tot = ap.take(sizeof(RegionTotal));
     const size_t o_runs = ap.take((size_t)len * sizeof(RunRec));
     const size_t o_out = ap.take(max_values * (size_t)esz + 64);
     const size_t o_ff = ap.total;
     const size_t o_te = ap.take((size_t)n_tiles * sizeof(TileEntry));
+    const size_t o_ge = ap.take((size_t)n_groups * sizeof(TileEntry));
     const size_t o_otf = ap.take((size_t)n_otiles * 4);
     const size_t ff_end = ap.total;
     const size_t o_zero = ap.total;
@@ -703,16 +727,18 @@ int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block_, size_t block_len
     Region R;
     memset(&R, 0, sizeof R);
     R.src_off = 0; R.len = (u32)len; R.width = (u32)width; R.n_out = 0; R.out = A + o_out; R.count_level = ERR_POS;
-    const u32 tp[2] = {0, n_tiles}, otp[2] = {0, n_otiles};
+    const u32 tp[2] = {0, n_tiles}, otp[2] = {0, n_otiles}, gp[2] = {0, n_groups};
+    const ChainArgs ca{(Region*)(A + o_reg), (u32*)(A + o_tp), (u32*)(A + o_gp), 1, n_tiles, n_groups, (ExitRec*)(A + o_exit),
+                       (ExitRec*)(A + o_gexit), (TileEntry*)(A + o_te), (TileEntry*)(A + o_ge), (RegionTotal*)(A + o_tot)};
     HIP_TRY(ctx, hipMemsetAsync(A + o_ff, 0xFF, ff_end - o_ff, st));
     HIP_TRY(ctx, hipMemsetAsync(A + o_zero, 0, ap.total - o_zero, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_src, block + 4, (size_t)len, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_reg, &R, sizeof R, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_tp, tp, 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_otp, otp, 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, A + o_src, (Region*)(A + o_reg), (u32*)(A + o_tp), 1, n_tiles, (ExitRec*)(A + o_exit),
-                              (TileEntry*)(A + o_te), (RegionTotal*)(A + o_tot), (RunRec*)(A + o_runs), (u32*)(A + o_otf),
-                              (PageDyn*)(A + o_pdyn), (int*)(A + o_status), 0));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_gp, gp, 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, A + o_src, ca, (RunRec*)(A + o_runs), (u32*)(A + o_otf), (PageDyn*)(A + o_pdyn),
+                              (int*)(A + o_status), 0));
     RegionTotal tot;
     int status[4];
     HIP_TRY(ctx, hipMemcpyAsync(&tot, A + o_tot, sizeof tot, hipMemcpyDeviceToHost, st));
@@ -727,9 +753,8 @@ int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block_, size_t block_len
     const u32 otp2[2] = {0, (u32)((n_emit + OT - 1) / OT)};
     HIP_TRY(ctx, hipMemcpyAsync(A + o_reg, &R, sizeof R, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_otp, otp2, 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, A + o_src, (Region*)(A + o_reg), (u32*)(A + o_tp), 1, n_tiles, (ExitRec*)(A + o_exit),
-                              (TileEntry*)(A + o_te), (RegionTotal*)(A + o_tot), (RunRec*)(A + o_runs), (u32*)(A + o_otf),
-                              (PageDyn*)(A + o_pdyn), (int*)(A + o_status), 1));
+    HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, A + o_src, ca, (RunRec*)(A + o_runs), (u32*)(A + o_otf), (PageDyn*)(A + o_pdyn),
+                              (int*)(A + o_status), 1));
     HIP_TRY(ctx, launch_levels_expand(st, esz, A + o_src, (Region*)(A + o_reg), (u32*)(A + o_otp), 1, otp2[1], (RunRec*)(A + o_runs),
                                       (u32*)(A + o_otf), (RegionTotal*)(A + o_tot), (PageDyn*)(A + o_pdyn)));
     HIP_TRY(ctx, hipMemcpyAsync(out_host, A + o_out, n_emit * (size_t)esz, hipMemcpyDeviceToHost, st));

@@ -11,6 +11,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 constexpr u32 ERR_POS = 0xFFFFFFFFu;
+constexpr u32 UNKNOWN_POS = 0xFFFFFFFEu;  // group exit not tabulated
 
 // device status codes (mapped to pqd_status by the host)
 constexpr int ST_CORRUPT = 1, ST_NONCANONICAL = 2, ST_UNSUPPORTED = 3;
@@ -39,6 +40,9 @@ constexpr u32 CH_E_LEVELS = 256;  // tabulated entry positions per tile: covers 
                                   // run (1 + 63 groups x 4 bytes); longer jumps take the serial hop
 constexpr u32 CH_E_STRINGS = 64;  // covers values up to 60 bytes; longer ones take the serial hop
 
+constexpr u32 CH_G_LEVELS = 8;    // tiles per hop group (level blocks are ~60 tiles per 1M-value page)
+constexpr u32 CH_G_STRINGS = 64;  // tiles per hop group (string pages are thousands of tiles)
+
 constexpr u32 OT = 4096;          // level values per expand tile
 constexpr u32 EX_CAP = 2048;      // runs staged in LDS per expand batch
 constexpr u32 BT = 4096;          // bools per tile
@@ -56,6 +60,8 @@ struct Region {
     u8* out;         // levels: destination of value 0; strings: the chunk's offsets array
     u32 page;        // page index
     u32 count_level; // levels: count values equal to this into page_dyn[page].nn; ERR_POS = do not count
+    u32 group_base;  // first hop group of the region in the global group numbering
+    u32 pad;
 };
 
 struct ExitRec { u32 tgt; u32 cnt; u64 vals; };
@@ -94,9 +100,19 @@ struct RowTile { u32 rows, vals; u64 row_base, val_base; };
 // ---- launchers -----------------------------------------------------------------------------
 hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32* blk_prefix, u32 n_segs, u32 n_blocks,
                        u32 max_grid);
-hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const Region* regions, const u32* tile_prefix,
-                        u32 n_regions, u32 n_tiles, ExitRec* exit_tbl, TileEntry* tile_entry, RegionTotal* totals,
-                        RunRec* run_tbl, u32* otile_first_run, const PageDyn* page_dyn, int* status, int phase);
+struct ChainArgs {
+    const Region* regions;
+    const u32* tile_prefix;   // n_regions + 1
+    const u32* group_prefix;  // n_regions + 1
+    u32 n_regions, n_tiles, n_groups;
+    ExitRec* exit_tbl;        // n_tiles * E
+    ExitRec* gexit;           // n_groups * E
+    TileEntry* tile_entry;    // n_tiles   (reset to 0xFF before every run)
+    TileEntry* group_entry;   // n_groups  (reset to 0xFF before every run)
+    RegionTotal* totals;      // n_regions
+};
+hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs& a, RunRec* run_tbl, u32* otile_first_run,
+                        const PageDyn* page_dyn, int* status, int phase);
 hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_prefix,
                                 u32 n_regions, u32 n_otiles, const RunRec* run_tbl, const u32* otile_first_run,
                                 const RegionTotal* totals, PageDyn* page_dyn);

@@ -100,8 +100,9 @@ __global__ __launch_bounds__(CP_THREADS) void k_copy(const u8* __restrict__ src_
 //                        and how many elements / level values it passes.  A second backward sweep over
 //                        the 64 sub-tiles turns these into tile exits.  The first E starts of each
 //                        tile go to an exit table.
-//   k_chain_resolve      hops from tile to tile through the exit table and records where the true
-//                        chain enters each tile.
+//   k_chain_groups / k_chain_resolve / k_chain_tiles
+//                        hop from tile to tile through the exit table (in three levels) and record
+//                        where the true chain enters each tile.
 //   k_chain<.., true>    same per-lane sweep; lane 0 then follows the true chain from sub-tile to
 //                        sub-tile (<= 64 hops), and every lane walks its sub-tile from its true entry,
 //                        emitting one record per true element.
@@ -372,12 +373,73 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
     }
 }
 
-// One thread per region: hop from tile to tile along the true chain.
+// ---- hopping from tile to tile along the true chain, in three levels so that no thread makes more
+// than a few dozen dependent loads:
+//   k_chain_groups    per group of G tiles and per tabulated entry of its first tile: where the chain
+//                     leaves the group (one lane per entry, <= G hops)
+//   k_chain_resolve   one thread per region hops from group to group and records the group entries
+//   k_chain_tiles     one thread per group hops through its tiles and records the tile entries
+
+// One hop: the chain is at region position p (p < L); returns where it leaves p's tile.
+template <int KIND>
+static __device__ __forceinline__ u32 hop_tile(const Region& R, const GlobalBytes& B, const ExitRec* __restrict__ exit_tbl,
+                                               u32 p, u32& cnt, u64& vals) {
+    constexpr u32 E = KIND == KIND_LEVELS ? CH_E_LEVELS : CH_E_STRINGS;
+    const u32 L = R.len, t = p / CH_T, off = p % CH_T;
+    if (off < E) {
+        const ExitRec x = exit_tbl[(u64)(R.tile_base + t) * E + off];
+        cnt += x.cnt; vals += x.vals;
+        return x.tgt;
+    }
+    // entry beyond the tabulated window: walk this tile element by element
+    const u32 tend = (t + 1) * CH_T < L ? (t + 1) * CH_T : L;
+    u32 q = p;
+    while (q < tend) {
+        u32 nxt; u64 v = 0;
+        if (KIND == KIND_LEVELS) { u32 info; rle_step(B, q, L, R.width, nxt, v, info); }
+        else str_step(B, q, L, nxt);
+        cnt++; vals += v;
+        q = nxt;
+    }
+    return q;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                                                     const u32* __restrict__ group_prefix, u32 n_regions,
+                                                     const ExitRec* __restrict__ exit_tbl, ExitRec* __restrict__ gexit) {
+    constexpr u32 E = KIND == KIND_LEVELS ? CH_E_LEVELS : CH_E_STRINGS;
+    constexpr u32 G = KIND == KIND_LEVELS ? CH_G_LEVELS : CH_G_STRINGS;
+    const u32 group = blockIdx.x / (E / 64);
+    const u32 i = (blockIdx.x % (E / 64)) * 64 + threadIdx.x;  // entry offset into the group's first tile
+    const u32 ri = find_owner(group_prefix, n_regions, group);
+    const Region R = regions[ri];
+    const u32 L = R.len;
+    const u32 g_lo = (group - group_prefix[ri]) * G * CH_T;
+    const u32 g_hi = g_lo + G * CH_T < L ? g_lo + G * CH_T : L;
+    const GlobalBytes B{src_base + R.src_off};
+    u32 p = g_lo + i, cnt = 0;
+    u64 vals = 0;
+    if (p >= g_hi) return;
+    // Only one of the E candidate entries is the true one; a candidate whose chain lands beyond the
+    // tabulated window of some tile is given up (UNKNOWN_POS) rather than walked byte by byte: if it was
+    // the true entry after all, k_chain_resolve hops that group tile by tile itself.
+    while (p < g_hi) {
+        if (p % CH_T >= E) { p = UNKNOWN_POS; break; }
+        p = hop_tile<KIND>(R, B, exit_tbl, p, cnt, vals);
+    }
+    ExitRec x;
+    x.tgt = p; x.cnt = cnt; x.vals = vals;
+    gexit[(u64)group * E + i] = x;
+}
+
 template <int KIND>
 __global__ void k_chain_resolve(const u8* __restrict__ src_base, const Region* __restrict__ regions, u32 n_regions,
-                                const ExitRec* __restrict__ exit_tbl, TileEntry* __restrict__ tile_entry,
-                                RegionTotal* __restrict__ totals, int* __restrict__ status) {
+                                const ExitRec* __restrict__ exit_tbl, const ExitRec* __restrict__ gexit,
+                                TileEntry* __restrict__ group_entry, RegionTotal* __restrict__ totals,
+                                int* __restrict__ status) {
     constexpr u32 E = KIND == KIND_LEVELS ? CH_E_LEVELS : CH_E_STRINGS;
+    constexpr u32 G = KIND == KIND_LEVELS ? CH_G_LEVELS : CH_G_STRINGS;
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_regions) return;
     const Region R = regions[r];
@@ -385,38 +447,54 @@ __global__ void k_chain_resolve(const u8* __restrict__ src_base, const Region* _
     const GlobalBytes B{src_base + R.src_off};
     u32 p = 0, cnt = 0;
     u64 vals = 0;
-    bool err = false;
     while (p < L) {
-        const u32 t = p / CH_T, off = p % CH_T;
-        TileEntry te;
-        te.pos = p; te.cnt = cnt; te.vals = vals;
-        tile_entry[R.tile_base + t] = te;
-        u32 tgt;
-        if (off < E) {
-            const ExitRec x = exit_tbl[(u64)(R.tile_base + t) * E + off];
-            tgt = x.tgt; cnt += x.cnt; vals += x.vals;
+        const u32 g = p / (G * CH_T), off = p - g * G * CH_T;
+        TileEntry ge;
+        ge.pos = p; ge.cnt = cnt; ge.vals = vals;
+        group_entry[R.group_base + g] = ge;
+        ExitRec x;
+        x.tgt = UNKNOWN_POS;
+        if (off < E) x = gexit[(u64)(R.group_base + g) * E + off];
+        if (x.tgt != UNKNOWN_POS) {
+            cnt += x.cnt; vals += x.vals;
+            p = x.tgt;
         } else {
-            // entry beyond the tabulated window: walk this tile element by element
-            const u32 tend = (t + 1) * CH_T < L ? (t + 1) * CH_T : L;
-            u32 q = p;
-            while (q < tend) {
-                u32 nxt; u64 v = 0;
-                if (KIND == KIND_LEVELS) { u32 info; rle_step(B, q, L, R.width, nxt, v, info); }
-                else str_step(B, q, L, nxt);
-                cnt++; vals += v;
-                q = nxt;
-                if (nxt == ERR_POS) break;
-            }
-            tgt = q;
+            const u32 g_hi = (g + 1) * G * CH_T < L ? (g + 1) * G * CH_T : L;
+            while (p < g_hi) p = hop_tile<KIND>(R, B, exit_tbl, p, cnt, vals);
         }
-        if (tgt == ERR_POS) { err = true; break; }
-        p = tgt;
     }
+    const bool err = p == ERR_POS;
     RegionTotal tot;
     tot.cnt = cnt; tot.err = err ? 1 : 0; tot.vals = vals;
     totals[r] = tot;
     if (err) set_status(status, ST_CORRUPT, r);
     else if (KIND == KIND_LEVELS && vals < R.n_out) set_status(status, ST_CORRUPT, r);  // defs[:NumValues] out of range
+}
+
+template <int KIND>
+__global__ void k_chain_tiles(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                              const u32* __restrict__ group_prefix, u32 n_regions, u32 n_groups,
+                              const ExitRec* __restrict__ exit_tbl, const TileEntry* __restrict__ group_entry,
+                              TileEntry* __restrict__ tile_entry) {
+    constexpr u32 G = KIND == KIND_LEVELS ? CH_G_LEVELS : CH_G_STRINGS;
+    const u32 group = blockIdx.x * blockDim.x + threadIdx.x;
+    if (group >= n_groups) return;
+    const TileEntry ge = group_entry[group];
+    if (ge.pos == ERR_POS) return;  // the true chain never starts an element in this group
+    const u32 ri = find_owner(group_prefix, n_regions, group);
+    const Region R = regions[ri];
+    const u32 L = R.len;
+    const u32 g_lo = (group - group_prefix[ri]) * G * CH_T;
+    const u32 g_hi = g_lo + G * CH_T < L ? g_lo + G * CH_T : L;
+    const GlobalBytes B{src_base + R.src_off};
+    u32 p = ge.pos, cnt = ge.cnt;
+    u64 vals = ge.vals;
+    while (p < g_hi) {
+        TileEntry te;
+        te.pos = p; te.cnt = cnt; te.vals = vals;
+        tile_entry[R.tile_base + p / CH_T] = te;
+        p = hop_tile<KIND>(R, B, exit_tbl, p, cnt, vals);
+    }
 }
 
 // =====================================================================================
@@ -859,39 +937,41 @@ hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32
     return hipSuccess;
 }
 
-hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const Region* regions, const u32* tile_prefix,
-                        u32 n_regions, u32 n_tiles, ExitRec* exit_tbl, TileEntry* tile_entry, RegionTotal* totals,
-                        RunRec* run_tbl, u32* otile_first_run, const PageDyn* page_dyn, int* status, int phase) {
-    if (n_regions == 0) return hipSuccess;
+template <int KIND>
+static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs& a, RunRec* run_tbl, u32* otile_first_run,
+                                 const PageDyn* page_dyn, int* status, int phase) {
+    constexpr u32 E = KIND == KIND_LEVELS ? CH_E_LEVELS : CH_E_STRINGS;
+    if (a.n_regions == 0) return hipSuccess;
     if (phase == 0) {
-        if (n_tiles) {
-            if (kind == KIND_LEVELS)
-                hipLaunchKernelGGL((k_chain<KIND_LEVELS, false>), dim3(n_tiles), dim3(CH_THREADS), 0, st, src, regions, tile_prefix,
-                                   n_regions, exit_tbl, tile_entry, run_tbl, otile_first_run, page_dyn);
-            else
-                hipLaunchKernelGGL((k_chain<KIND_STRINGS, false>), dim3(n_tiles), dim3(CH_THREADS), 0, st, src, regions, tile_prefix,
-                                   n_regions, exit_tbl, tile_entry, run_tbl, otile_first_run, page_dyn);
+        if (a.n_tiles) {
+            hipLaunchKernelGGL((k_chain<KIND, false>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix,
+                               a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL((k_chain_groups<KIND>), dim3(a.n_groups * (E / 64)), dim3(64), 0, st, src, a.regions,
+                               a.group_prefix, a.n_regions, a.exit_tbl, a.gexit);
             LAUNCH_CHECK();
         }
-        // the hop kernel also runs for empty regions: it writes their (zero) totals
-        const u32 g = (n_regions + 63) / 64;
-        if (kind == KIND_LEVELS)
-            hipLaunchKernelGGL((k_chain_resolve<KIND_LEVELS>), dim3(g), dim3(64), 0, st, src, regions, n_regions, exit_tbl,
-                               tile_entry, totals, status);
-        else
-            hipLaunchKernelGGL((k_chain_resolve<KIND_STRINGS>), dim3(g), dim3(64), 0, st, src, regions, n_regions, exit_tbl,
-                               tile_entry, totals, status);
+        // the region hop also runs for empty regions: it writes their (zero) totals
+        hipLaunchKernelGGL((k_chain_resolve<KIND>), dim3((a.n_regions + 63) / 64), dim3(64), 0, st, src, a.regions, a.n_regions,
+                           a.exit_tbl, a.gexit, a.group_entry, a.totals, status);
         LAUNCH_CHECK();
-    } else if (n_tiles) {
-        if (kind == KIND_LEVELS)
-            hipLaunchKernelGGL((k_chain<KIND_LEVELS, true>), dim3(n_tiles), dim3(CH_THREADS), 0, st, src, regions, tile_prefix,
-                               n_regions, exit_tbl, tile_entry, run_tbl, otile_first_run, page_dyn);
-        else
-            hipLaunchKernelGGL((k_chain<KIND_STRINGS, true>), dim3(n_tiles), dim3(CH_THREADS), 0, st, src, regions, tile_prefix,
-                               n_regions, exit_tbl, tile_entry, run_tbl, otile_first_run, page_dyn);
+        if (a.n_tiles) {
+            hipLaunchKernelGGL((k_chain_tiles<KIND>), dim3((a.n_groups + 63) / 64), dim3(64), 0, st, src, a.regions,
+                               a.group_prefix, a.n_regions, a.n_groups, a.exit_tbl, a.group_entry, a.tile_entry);
+            LAUNCH_CHECK();
+        }
+    } else if (a.n_tiles) {
+        hipLaunchKernelGGL((k_chain<KIND, true>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix,
+                           a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn);
         LAUNCH_CHECK();
     }
     return hipSuccess;
+}
+
+hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs& a, RunRec* run_tbl, u32* otile_first_run,
+                        const PageDyn* page_dyn, int* status, int phase) {
+    return kind == KIND_LEVELS ? launch_chain_t<KIND_LEVELS>(st, src, a, run_tbl, otile_first_run, page_dyn, status, phase)
+                               : launch_chain_t<KIND_STRINGS>(st, src, a, run_tbl, otile_first_run, page_dyn, status, phase);
 }
 
 hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_prefix,
