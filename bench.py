@@ -32,10 +32,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pages", type=int, default=32, help="pages per column chunk (1M rows each)")
+    ap.add_argument("--pages", type=int, default=None, help="pages per column chunk (default 32 for flat, 8 otherwise)")
     ap.add_argument("--row-groups", type=int, default=2)
     ap.add_argument("--rows-per-page", type=int, default=1_000_000)
-    ap.add_argument("--workload", default="flat", choices=["flat", "optional", "nested"])
+    ap.add_argument("--workload", default="flat", choices=["flat", "optional", "optint", "optstr", "nested"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--pcie", action="store_true", help="also measure the rate including H2D and D2H copies")
@@ -68,11 +68,12 @@ def build_flat_file(rg_ids, pages, rows_per_page):
     return buf
 
 
-def build_optional_file(rg_ids, pages, rows_per_page):
+def build_optional_file(rg_ids, pages, rows_per_page, which="both"):
     """configs[2]: optional int32 and string columns, 10 % nulls (def level width 1)."""
     from parquet_amd import _native as N
     from parquet_amd.writer import Column, ParquetWriter
     cols = [Column("oi32", N.INT32, [1]), Column("ostr", N.BYTE_ARRAY, [1])]
+    cols = {"both": cols, "int": cols[:1], "str": cols[1:]}[which]
     w = ParquetWriter(cols, stats=True)
     for g in rg_ids:
         rng = np.random.default_rng(2000 + g)
@@ -185,8 +186,10 @@ def main():
     from parquet_amd import _native as N
     from parquet_amd import reader as R
 
-    builders = {"flat": build_flat_file, "optional": build_optional_file, "nested": build_nested_file}
-    pages = args.pages if args.workload == "flat" else min(args.pages, 8)
+    builders = {"flat": build_flat_file, "optional": build_optional_file, "nested": build_nested_file,
+                "optint": lambda *a: build_optional_file(*a, which="int"),
+                "optstr": lambda *a: build_optional_file(*a, which="str")}
+    pages = args.pages or (32 if args.workload == "flat" else 8)
     t_build = time.perf_counter()
     # The job's file has world * row_groups row groups (weak scaling); whole row groups go to ranks in
     # contiguous ranges balanced by payload bytes, and each rank materialises only its own shard.
@@ -287,6 +290,8 @@ def main():
                     "flat": "configs[1]: flat required int32/int64/float64 columns, %d rows/page, %d pages/chunk, %d row groups per GPU (uncompressed DATA_PAGE v1, PLAIN)",
                     "optional": "configs[2]: optional int32 + string columns, 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
                     "nested": "configs[3]: Person{Being,Friends []Being} int32 leaves, %d rows/page, %d pages/chunk, %d row groups per GPU",
+                    "optint": "configs[2], int32 half: optional int32 column, 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
+                    "optstr": "configs[2], string half: optional string column (8-32 B), 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
                 }[args.workload] % (args.rows_per_page, pages, args.row_groups),
                 "file_bytes_per_gpu": pf.size,
                 "algorithmic_bytes_per_step_per_gpu": alg,

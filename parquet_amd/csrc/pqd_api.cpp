@@ -288,10 +288,12 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         if (C.max_def > 0) {
             want(PQD_OUT_DEFS, C.n_levels);
             want(PQD_OUT_VALIDITY, (C.n_levels + 7) / 8);
+        }
+        if (C.max_rep > 0) {
+            want(PQD_OUT_REPS, C.n_levels);
             want(PQD_OUT_ROW_LEVEL_OFF, (C.n_levels + 1) * 8);
             want(PQD_OUT_ROW_VALUE_OFF, (C.n_levels + 1) * 8);
         }
-        if (C.max_rep > 0) want(PQD_OUT_REPS, C.n_levels);
         if (C.width_bytes) want(PQD_OUT_VALUES, C.stream_len);
         else if (C.phys_type == PQD_BOOLEAN) want(PQD_OUT_VALUES, C.n_levels);
         else {

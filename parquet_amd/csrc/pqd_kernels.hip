@@ -848,6 +848,7 @@ __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunk
     const u32 rt = blockIdx.x;
     const u32 k = find_owner(rtile_prefix, n_rchunks, rt);
     const ChunkRec C = chunks[chunk_ids[k]];
+    if (WRITE && C.max_rep == 0) return;  // rows == levels: no offsets are materialised
     const u64 n = C.n_levels;
     const u64 i0 = (u64)(rt - rtile_prefix[k]) * RT + threadIdx.x * 16;
     u32 valid = 0, starts = 0;
@@ -918,8 +919,10 @@ __global__ __launch_bounds__(64) void k_rows_scan(const ChunkRec* __restrict__ c
     }
     if (lane == 0) {
         chunk_dyn[c].n_rows = run_r;
-        ((u64*)C.row_level_off)[run_r] = C.n_levels;
-        ((u64*)C.row_value_off)[run_r] = run_v;
+        if (C.max_rep > 0) {
+            ((u64*)C.row_level_off)[run_r] = C.n_levels;
+            ((u64*)C.row_value_off)[run_r] = run_v;
+        }
     }
 }
 

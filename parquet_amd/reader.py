@@ -188,10 +188,16 @@ class Plan:
         if cd.max_def > 0:
             out["defs"] = self.fetch(chunk, N.OUT_DEFS)
             out["validity"] = self.fetch(chunk, N.OUT_VALIDITY)
-            out["row_level_off"] = self.fetch(chunk, N.OUT_ROW_LEVEL_OFF, np.int64)
-            out["row_value_off"] = self.fetch(chunk, N.OUT_ROW_VALUE_OFF, np.int64)
         if cd.max_rep > 0:
             out["reps"] = self.fetch(chunk, N.OUT_REPS)
+            out["row_level_off"] = self.fetch(chunk, N.OUT_ROW_LEVEL_OFF, np.int64)
+            out["row_value_off"] = self.fetch(chunk, N.OUT_ROW_VALUE_OFF, np.int64)
+        elif cd.max_def > 0:
+            # not repeated: row r is level r (write_optional.go:22-31); its first value is the number of
+            # non-null levels before it
+            n = out["defs"].size
+            out["row_level_off"] = np.arange(n + 1, dtype=np.int64)
+            out["row_value_off"] = np.concatenate(([0], np.cumsum(out["defs"] == cd.max_def, dtype=np.int64)))
         out["sizes"] = self.fetch(chunk, N.OUT_PAGE_NONNULL, np.int64)
         if cd.phys_type == N.BYTE_ARRAY:
             out["offsets"] = self.fetch(chunk, N.OUT_OFFSETS, np.int32)
