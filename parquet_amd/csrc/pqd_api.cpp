@@ -71,7 +71,7 @@ struct pqd_plan {
     TileEntry *d_ltile_entry = nullptr, *d_stile_entry = nullptr, *d_lgroup_entry = nullptr, *d_sgroup_entry = nullptr;
     ChainArgs lchain = {}, schain = {};
     RegionTotal *d_ltotals = nullptr, *d_stotals = nullptr;
-    RunRec* d_runs = nullptr; u32* d_otile_first = nullptr;
+    RunRec* d_runs = nullptr; u32* d_otile_first = nullptr; u32* d_otile_cnt = nullptr;
     PageDyn* d_page_dyn = nullptr; ChunkDyn* d_chunk_dyn = nullptr; RowTile* d_row_tiles = nullptr;
     int* d_status = nullptr;
     u8 *ff_begin = nullptr, *zero_begin = nullptr;  // per-run reset ranges
@@ -408,6 +408,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_stot = ap.take(pl->sregions.size() * sizeof(RegionTotal));
     const size_t o_runs = ap.take((size_t)run_base * sizeof(RunRec));
     const size_t o_rtiles = ap.take((size_t)pl->n_rtiles * sizeof(RowTile));
+    const size_t o_otc = ap.take((size_t)pl->n_lotiles * 4);
     const size_t o_cdyn = ap.take(n_chunks * sizeof(ChunkDyn));
     // reset to 0xFF every run
     const size_t o_ff = ap.total;
@@ -491,6 +492,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->d_chunk_dyn = (ChunkDyn*)(A + o_cdyn);
     pl->d_ltile_entry = (TileEntry*)(A + o_lte); pl->d_stile_entry = (TileEntry*)(A + o_ste);
     pl->d_otile_first = (u32*)(A + o_otf);
+    pl->d_otile_cnt = (u32*)(A + o_otc);
     pl->d_page_dyn = (PageDyn*)(A + o_pdyn); pl->d_status = (int*)(A + o_status);
     pl->d_segs = (Seg*)(A + o_segs); pl->d_seg_blk_prefix = (u32*)(A + o_segp);
     pl->ff_begin = A + o_ff; pl->ff_bytes = ff_end - o_ff;
@@ -555,7 +557,7 @@ int pqd_plan_run(pqd_plan* pl, const void* src_device) {
         HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, src, pl->lchain, pl->d_runs, pl->d_otile_first, pl->d_page_dyn, pl->d_status, 0));
         HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, src, pl->lchain, pl->d_runs, pl->d_otile_first, pl->d_page_dyn, pl->d_status, 1));
         HIP_TRY(ctx, launch_levels_expand(st, 1, src, pl->d_lregions, pl->d_lotile_prefix, n_lreg, pl->n_lotiles, pl->d_runs,
-                                          pl->d_otile_first, pl->d_ltotals, pl->d_page_dyn));
+                                          pl->d_otile_first, pl->d_ltotals, pl->d_otile_cnt, pl->d_page_dyn));
     }
     HIP_TRY(ctx, launch_page_scan(st, pl->d_chunks, n_chunks, pl->d_pages, n_pages, pl->d_page_dyn, pl->d_chunk_dyn, pl->d_status));
     HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, (u32)pl->bool_pages.size(), pl->n_btiles,
@@ -758,7 +760,7 @@ int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block_, size_t block_len
     HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, A + o_src, ca, (RunRec*)(A + o_runs), (u32*)(A + o_otf), (PageDyn*)(A + o_pdyn),
                               (int*)(A + o_status), 1));
     HIP_TRY(ctx, launch_levels_expand(st, esz, A + o_src, (Region*)(A + o_reg), (u32*)(A + o_otp), 1, otp2[1], (RunRec*)(A + o_runs),
-                                      (u32*)(A + o_otf), (RegionTotal*)(A + o_tot), (PageDyn*)(A + o_pdyn)));
+                                      (u32*)(A + o_otf), (RegionTotal*)(A + o_tot), nullptr, (PageDyn*)(A + o_pdyn)));
     HIP_TRY(ctx, hipMemcpyAsync(out_host, A + o_out, n_emit * (size_t)esz, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return PQD_OK;

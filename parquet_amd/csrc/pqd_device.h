@@ -115,7 +115,7 @@ hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs
                         const PageDyn* page_dyn, int* status, int phase);
 hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_prefix,
                                 u32 n_regions, u32 n_otiles, const RunRec* run_tbl, const u32* otile_first_run,
-                                const RegionTotal* totals, PageDyn* page_dyn);
+                                const RegionTotal* totals, u32* otile_cnt, PageDyn* page_dyn);
 hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks, const PageRec* pages, u32 n_pages,
                             PageDyn* page_dyn, ChunkDyn* chunk_dyn, int* status);
 hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids, const u32* btile_prefix,

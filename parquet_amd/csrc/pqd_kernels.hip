@@ -346,7 +346,16 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
             if (KIND == KIND_LEVELS) {
                 u32 info;
                 u64 vals;
-                rle_step_win(win64(w, k), q, L, R.width, nxt, vals, info);
+                const u64 x = win64(w, k);
+                rle_step_win(x, q, L, R.width, nxt, vals, info);
+                if (!(info & 1) && R.width <= 8) {
+                    // RLE run of a narrow level: the record carries the value itself (width 0: value 0)
+                    const u32 vp = info >> 1, d = vp - q;
+                    u32 val = 0;
+                    if (R.width > 0 && nxt != ERR_POS) val = d < 8 ? (u32)(x >> (8 * d)) & 0xFF : (u32)rsrc[vp];
+                    info = val << 1;
+                }
+                if ((info & 1) && R.width == 0) info = 0;  // width 0 bit-packed groups are runs of zeros
                 RunRec rr;
                 rr.out_off = o < n_out ? (u32)o : (u32)n_out;
                 rr.info = info;
@@ -513,11 +522,12 @@ template <int ESZ>
 __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                        const u32* __restrict__ otile_prefix, u32 n_regions,
                                                        const RunRec* __restrict__ run_tbl, const u32* __restrict__ otile_first_run,
-                                                       const RegionTotal* __restrict__ totals, PageDyn* __restrict__ page_dyn) {
+                                                       const RegionTotal* __restrict__ totals, u32* __restrict__ otile_cnt) {
     __shared__ u32 s_out[EX_CAP + 1];
     __shared__ u32 s_info[EX_CAP];
-    __shared__ u32 s_ctl[2];
-    const u32 tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) unsigned short s_mark[OT];
+    __shared__ u32 s_wave[4];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 ot = blockIdx.x;
     const u32 ri = find_owner(otile_prefix, n_regions, ot);
     const Region R = regions[ri];
@@ -530,101 +540,112 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
     u32 first = otile_first_run[ot];
     if (first == ERR_POS || totals[ri].err) return;  // short or corrupt block: status already set
     const RunRec* runs = run_tbl + R.run_base;
+    // the runs this tile needs end with the run that owns the first value of the next tile
+    u32 last = n_runs;  // exclusive
+    if (ot + 1 < otile_prefix[ri + 1]) {
+        const u32 nf = otile_first_run[ot + 1];
+        if (nf != ERR_POS && nf + 1 < last) last = nf + 1;
+    }
 
-    // this thread's 16 (ESZ == 1) or 16/ESZ... values: always 16 values per thread
-    const u32 o0 = t_lo + tid * 16;
-    u64 acc_lo = 0, acc_hi = 0;           // ESZ == 1: 16 result bytes
-    u32 wide[ESZ == 1 ? 1 : 16];          // ESZ > 1: results (static indexing only)
-    u32 cur = t_lo;                        // everything below `cur` is done
-    while (cur < t_hi) {
-        // stage up to EX_CAP runs starting at `first`
+    const u32 o0 = t_lo + tid * 16;  // this thread's 16 values
+    u64 acc_lo = 0, acc_hi = 0;      // ESZ == 1: the 16 result bytes
+    u32 wide[ESZ == 1 ? 1 : 16];     // ESZ > 1: results (static indexing only)
+    u32 cur = t_lo;                  // everything below `cur` is done
+    for (;;) {
+        // stage up to EX_CAP runs starting at `first`; they cover [cur, batch_hi)
         __syncthreads();
-        const u32 m = n_runs - first < EX_CAP ? n_runs - first : EX_CAP;
+        const u32 m = last - first < EX_CAP ? last - first : EX_CAP;
         if (m == 0) break;
         for (u32 i = tid; i < m; i += 256) {
             const RunRec rr = runs[first + i];
             s_out[i] = rr.out_off;
             s_info[i] = rr.info;
         }
-        if (tid == 0) {
-            // end of the range the staged runs cover
-            s_out[m] = first + m < n_runs ? runs[first + m].out_off : n_out;
-        }
+        if (tid == 0) s_out[m] = first + m < n_runs ? runs[first + m].out_off : n_out;
+        // clear the marks (16 per thread)
+        *(u32x4*)(s_mark + tid * 16) = u32x4{0, 0, 0, 0};
+        *(u32x4*)(s_mark + tid * 16 + 8) = u32x4{0, 0, 0, 0};
         __syncthreads();
         const u32 batch_hi = s_out[m] < t_hi ? s_out[m] : t_hi;
-        // my values inside [max(cur,o0), min(batch_hi, o0+16))
-        u32 lo = o0 > cur ? o0 : cur;
-        u32 hi = o0 + 16 < batch_hi ? o0 + 16 : batch_hi;
-        if (lo < hi) {
-            // last staged run with out_off <= lo
-            u32 a = 0, b = m;
-            while (b - a > 1) { const u32 mid = (a + b) >> 1; if (s_out[mid] <= lo) a = mid; else b = mid; }
-            u32 j = a;
-            u32 oo = lo;
-            while (oo < hi) {
-                while (s_out[j + 1] <= oo) j++;
-                const u32 seg_hi = s_out[j + 1] < hi ? s_out[j + 1] : hi;
-                const u32 info = s_info[j];
-                const u32 pos = info >> 1;
-                if ((info & 1) == 0 || w == 0) {
-                    // RLE run: value in ceil(w/8) little-endian bytes
-                    u32 val = 0;
-                    const u32 bw = (w + 7) >> 3;
-                    for (u32 k = 0; k < bw; k++) val |= (u32)rsrc[pos + k] << (8 * k);
-                    if (ESZ == 1) {
-                        const u64 splat = (u64)(val & 0xFF) * 0x0101010101010101ull;
-                        for (u32 x = oo; x < seg_hi; x++) {
-                            const u32 kk = x - o0;
-                            if (kk < 8) acc_lo |= (splat & 0xFFull) << (8 * kk); else acc_hi |= (splat & 0xFFull) << (8 * (kk - 8));
-                        }
-                    } else {
+        // every run that holds values marks the position where it starts (run 0 holds position `cur`);
+        // runs without values never own a position, so no two runs mark the same one
+        for (u32 i = tid; i < m; i += 256) {
+            const u32 o = s_out[i], oe = s_out[i + 1];
+            const u32 start = i == 0 ? cur : o;
+            if (oe > start && start < batch_hi && start >= cur) s_mark[start - t_lo] = (unsigned short)(i + 1);
+        }
+        __syncthreads();
+        // running maximum of the marks = (index + 1) of the run that owns each position
+        u32 rk[16];
+        {
+            const u32x4 a = *(const u32x4*)(s_mark + tid * 16), b = *(const u32x4*)(s_mark + tid * 16 + 8);
+            const u32 words[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            u32 run = 0;
 #pragma unroll
-                        for (int kk = 0; kk < 16; kk++) if (o0 + kk >= oo && o0 + kk < seg_hi) wide[kk] = val;
-                    }
-                } else {
-                    // bit-packed run: value idx sits at bit idx*w of the packed bytes (LSB first)
-                    const u32 idx0 = oo - s_out[j];
-                    if (ESZ == 1) {
-                        u32 x = oo;
-                        while (x < seg_hi) {
-                            const u32 n = seg_hi - x < 8 ? seg_hi - x : 8;
-                            const u64 bit = (u64)(idx0 + (x - oo)) * w;
-                            const u64 win = load_u64_guarded(rsrc, pos + (u32)(bit >> 3), L) >> (bit & 7);
-                            const u32 mask = (1u << w) - 1;
-                            for (u32 q = 0; q < n; q++) {
-                                const u64 v = (win >> (q * w)) & mask;
-                                const u32 kk = x + q - o0;
-                                if (kk < 8) acc_lo |= v << (8 * kk); else acc_hi |= v << (8 * (kk - 8));
-                            }
-                            x += n;
-                        }
-                    } else {
+            for (int k = 0; k < 16; k++) {
+                const u32 mk = (words[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
+                run = mk > run ? mk : run;
+                rk[k] = run;
+            }
+            u32 incl = run;
+            for (int d = 1; d < 64; d <<= 1) {
+                const u32 t = __shfl_up(incl, d);
+                if (lane >= (u32)d && t > incl) incl = t;
+            }
+            if (lane == 63) s_wave[wv] = incl;
+            u32 carry = __shfl_up(incl, 1);
+            if (lane == 0) carry = 0;
+            __syncthreads();
+            for (u32 q = 0; q < wv; q++) carry = s_wave[q] > carry ? s_wave[q] : carry;
 #pragma unroll
-                        for (int kk = 0; kk < 16; kk++) {
-                            if (o0 + kk >= oo && o0 + kk < seg_hi) {
-                                const u64 bit = (u64)(idx0 + (o0 + kk - oo)) * w;
-                                const u64 win = load_u64_guarded(rsrc, pos + (u32)(bit >> 3), L) >> (bit & 7);
-                                wide[kk] = w == 32 ? (u32)win : (u32)(win & ((1ull << w) - 1));
-                            }
+            for (int k = 0; k < 16; k++) rk[k] = rk[k] > carry ? rk[k] : carry;
+        }
+        // decode my positions inside [cur, batch_hi)
+        u32 cur_r = 0, r_out = 0, r_info = 0, rle_val = 0, win_bit0 = 0;
+        u64 win = 0;
+        bool win_ok = false;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u32 pos = o0 + k;
+            if (pos >= cur && pos < batch_hi) {
+                const u32 r = rk[k];
+                if (r != cur_r) {
+                    cur_r = r;
+                    r_out = s_out[r - 1];
+                    r_info = s_info[r - 1];
+                    win_ok = false;
+                    if (!(r_info & 1)) {
+                        if (w <= 8) rle_val = r_info >> 1;  // value stored in the record
+                        else {
+                            rle_val = 0;
+                            const u32 bw = (w + 7) >> 3;
+                            for (u32 b = 0; b < bw; b++) rle_val |= (u32)rsrc[(r_info >> 1) + b] << (8 * b);
                         }
                     }
                 }
-                oo = seg_hi;
+                u32 v;
+                if (!(r_info & 1)) v = rle_val;
+                else {
+                    // bit-packed: value idx sits at bit idx*w of the packed bytes, LSB first
+                    const u64 bit = (u64)(pos - r_out) * w;
+                    if (!win_ok || bit < win_bit0 || bit - win_bit0 + w > 64) {
+                        const u32 byte = (u32)(bit >> 3);
+                        win = load_u64_guarded(rsrc, (r_info >> 1) + byte, L);
+                        win_bit0 = byte * 8;
+                        win_ok = true;
+                    }
+                    const u64 x = win >> (bit - win_bit0);
+                    v = w == 32 ? (u32)x : (u32)(x & ((1ull << w) - 1));
+                }
+                if (ESZ == 1) {
+                    if (k < 8) acc_lo |= (u64)(v & 0xFF) << (8 * k); else acc_hi |= (u64)(v & 0xFF) << (8 * (k - 8));
+                } else wide[k] = v;
             }
         }
         if (batch_hi >= t_hi) break;
-        // next batch: continue from the first run that reaches past batch_hi
-        if (tid == 0) {
-            u32 a = 0, b = m;  // last staged run with out_off <= batch_hi
-            while (b - a > 1) { const u32 mid = (a + b) >> 1; if (s_out[mid] <= batch_hi) a = mid; else b = mid; }
-            s_ctl[0] = s_out[m] <= batch_hi ? first + m : first + a;
-            s_ctl[1] = batch_hi;
-        }
-        __syncthreads();
-        const u32 nf = s_ctl[0];
-        if (nf == first && s_ctl[1] == cur) break;  // no progress (cannot happen for a consistent table)
-        first = nf;
-        cur = s_ctl[1];
+        // next batch starts with the run that owns position batch_hi
+        first += m;
+        cur = batch_hi;
     }
 
     // store + count
@@ -640,15 +661,20 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
             for (u32 k = 0; k < n_mine; k++) dst[k] = (u8)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8)));
         }
         if (R.count_level != ERR_POS) {
+            // bytes equal to count_level: XOR, then detect zero bytes
             const u64 cl = (u64)(R.count_level & 0xFF) * 0x0101010101010101ull;
-            u32 c = 0;
-            for (u32 k = 0; k < n_mine; k++) {
-                const u32 byte = (u32)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8))) & 0xFF;
-                c += byte == (u32)(cl & 0xFF);
-            }
-            // wave sum, then one atomic per wave
+            const u64 keep_lo = n_mine >= 8 ? ~0ull : (n_mine ? (1ull << (8 * n_mine)) - 1 : 0);
+            const u64 keep_hi = n_mine >= 16 ? ~0ull : (n_mine > 8 ? (1ull << (8 * (n_mine - 8))) - 1 : 0);
+            auto zero_bytes = [](u64 x) {  // 0x80 in every byte of x that is zero
+                return ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) & 0x8080808080808080ull;
+            };
+            u32 c = __popcll(zero_bytes(acc_lo ^ cl) & keep_lo) + __popcll(zero_bytes(acc_hi ^ cl) & keep_hi);
             for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
-            if ((tid & 63) == 0 && c) atomicAdd(&page_dyn[R.page].nn, c);
+            // one count per tile, summed per page by k_page_nn (no same-address atomics)
+            __syncthreads();
+            if (lane == 0) s_wave[wv] = c;
+            __syncthreads();
+            if (tid == 0) otile_cnt[ot] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         }
     } else if (ESZ == 2) {
         unsigned short* dst = (unsigned short*)R.out + o0;
@@ -659,6 +685,20 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
 #pragma unroll
         for (int k = 0; k < 16; k++) if ((u32)k < n_mine) dst[k] = wide[k];
     }
+}
+
+// Sums the per-tile counts of def == max_def into the page's non-null count (valsFromDefs).
+__global__ __launch_bounds__(64) void k_page_nn(const Region* __restrict__ regions, const u32* __restrict__ otile_prefix,
+                                                u32 n_regions, const u32* __restrict__ otile_cnt,
+                                                const RegionTotal* __restrict__ totals, PageDyn* __restrict__ page_dyn) {
+    const u32 r = blockIdx.x;
+    const Region R = regions[r];
+    if (R.count_level == ERR_POS) return;
+    u32 c = 0;
+    if (!totals[r].err)
+        for (u32 t = otile_prefix[r] + threadIdx.x; t < otile_prefix[r + 1]; t += 64) c += otile_cnt[t];
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    if (threadIdx.x == 0) page_dyn[R.page].nn = c;
 }
 
 // =====================================================================================
@@ -901,6 +941,10 @@ __global__ __launch_bounds__(64) void k_rows_scan(const ChunkRec* __restrict__ c
     if (k >= n_rchunks) return;
     const u32 c = chunk_ids[k];
     const ChunkRec C = chunks[c];
+    if (C.max_rep == 0) {  // not repeated: every level is a row
+        if (threadIdx.x == 0) chunk_dyn[c].n_rows = C.n_levels;
+        return;
+    }
     const u32 t0 = rtile_prefix[k], t1 = rtile_prefix[k + 1];
     const u32 lane = threadIdx.x;
     u64 run_r = 0, run_v = 0;
@@ -979,18 +1023,22 @@ hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs
 
 hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_prefix,
                                 u32 n_regions, u32 n_otiles, const RunRec* run_tbl, const u32* otile_first_run,
-                                const RegionTotal* totals, PageDyn* page_dyn) {
+                                const RegionTotal* totals, u32* otile_cnt, PageDyn* page_dyn) {
     if (n_otiles == 0) return hipSuccess;
     if (esz == 1)
         hipLaunchKernelGGL((k_levels_expand<1>), dim3(n_otiles), dim3(256), 0, st, src, regions, otile_prefix, n_regions, run_tbl,
-                           otile_first_run, totals, page_dyn);
+                           otile_first_run, totals, otile_cnt);
     else if (esz == 2)
         hipLaunchKernelGGL((k_levels_expand<2>), dim3(n_otiles), dim3(256), 0, st, src, regions, otile_prefix, n_regions, run_tbl,
-                           otile_first_run, totals, page_dyn);
+                           otile_first_run, totals, otile_cnt);
     else
         hipLaunchKernelGGL((k_levels_expand<4>), dim3(n_otiles), dim3(256), 0, st, src, regions, otile_prefix, n_regions, run_tbl,
-                           otile_first_run, totals, page_dyn);
+                           otile_first_run, totals, otile_cnt);
     LAUNCH_CHECK();
+    if (otile_cnt) {
+        hipLaunchKernelGGL(k_page_nn, dim3(n_regions), dim3(64), 0, st, regions, otile_prefix, n_regions, otile_cnt, totals, page_dyn);
+        LAUNCH_CHECK();
+    }
     return hipSuccess;
 }
 
