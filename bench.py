@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--pcie", action="store_true", help="also measure the rate including H2D and D2H copies")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo lets several ranks share one GPU (rehearsal of the N>1 path on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -178,10 +180,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decoder has no CPU path")
+    if args.dist_backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
 
     from parquet_amd import _native as N
     from parquet_amd import reader as R
@@ -205,8 +213,8 @@ def main():
     assert d_src
     assert N.decode.pqd_copy_to_device(ctx.handle, d_src, pf.address, pf.size) == 0
 
-    rows_local = torch.tensor([pf.num_rows], dtype=torch.int64, device="cuda")
-    rows_all = torch.zeros(world, dtype=torch.int64, device="cuda")
+    rows_local = torch.tensor([pf.num_rows], dtype=torch.int64, device=coll_dev)
+    rows_all = torch.zeros(world, dtype=torch.int64, device=coll_dev)
 
     def step():
         if world > 1:
@@ -242,13 +250,13 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     bytes_in, bytes_out, copy_bytes = plan.bytes()
     alg = bytes_in + bytes_out
-    alg_t = torch.tensor([alg], dtype=torch.int64, device="cuda")
+    alg_t = torch.tensor([alg], dtype=torch.int64, device=coll_dev)
     if world > 1:
         dist.all_reduce(alg_t)
     total_alg = int(alg_t.item())

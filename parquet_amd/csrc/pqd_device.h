@@ -44,7 +44,7 @@ constexpr u32 CH_G_LEVELS = 8;    // tiles per hop group (level blocks are ~60 t
 constexpr u32 CH_G_STRINGS = 64;  // tiles per hop group (string pages are thousands of tiles)
 
 constexpr u32 OT = 4096;          // level values per expand tile
-constexpr u32 EX_CAP = 2048;      // runs staged in LDS per expand batch
+constexpr u32 EX_CAP = 1024;      // runs staged in LDS per expand batch
 constexpr u32 BT = 4096;          // bools per tile
 constexpr u32 ST = 4096;          // string chars per gather tile
 constexpr u32 RT = 4096;          // levels per row-offset tile
