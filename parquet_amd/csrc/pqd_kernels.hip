@@ -236,15 +236,23 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
     // my sub-tile and 8 bytes of lookahead, in registers; bytes at or past L read as 0
     const u32 sub_lo = tb + lane * CH_SUB, sub_hi = sub_lo + CH_SUB;
     u32 w[CH_WIN];
+    if (sub_lo + 4 * CH_WIN <= L) {
+        // whole window inside the region: three independent wide loads (any alignment)
+        const u32x4 a = *(const u32x4_u*)(rsrc + sub_lo), b = *(const u32x4_u*)(rsrc + sub_lo + 16);
+        const u64 c = *(const u64_u*)(rsrc + sub_lo + 32);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        w[8] = (u32)c; w[9] = (u32)(c >> 32);
+    } else {
 #pragma unroll
-    for (int d = 0; d < (int)CH_WIN; d++) {
-        const u32 p = sub_lo + 4 * d;
-        u32 v = 0;
-        if (p < L) {
-            if (L - p >= 4) v = *(const u32_u*)(rsrc + p);
-            else for (u32 k = 0; k < L - p; k++) v |= (u32)rsrc[p + k] << (8 * k);
+        for (int d = 0; d < (int)CH_WIN; d++) {
+            const u32 p = sub_lo + 4 * d;
+            u32 v = 0;
+            if (p < L) {
+                if (L - p >= 4) v = *(const u32_u*)(rsrc + p);
+                else for (u32 k = 0; k < L - p; k++) v |= (u32)rsrc[p + k] << (8 * k);
+            }
+            w[d] = v;
         }
-        w[d] = v;
     }
 
     // ---- sweep 1: every start of my sub-tile learns where its chain leaves the sub-tile
@@ -339,6 +347,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
     u32 rank = e_cnt[lane];  // index of the element within the region
     u64 o = e_val[lane];     // levels: index of the run's first level value
     const u64 n_out = R.n_out;
+    PageDyn pd = {};
+    if (KIND == KIND_STRINGS) pd = page_dyn[R.page];
 #pragma unroll
     for (int k = 0; k < (int)CH_SUB; k++) {
         if (q == sub_lo + k && q < L) {
@@ -371,7 +381,6 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
                 // string `rank` of the page starts at q: its chars begin at q + 4; every earlier string of
                 // the page contributed 4 length bytes.  A page never holds more values than levels.
                 if (rank < n_out) {
-                    const PageDyn pd = page_dyn[R.page];
                     int32_t* offsets = (int32_t*)R.out;
                     offsets[pd.val_off + rank] = (int32_t)(pd.char_off + (u64)q - 4ull * rank);
                 }

@@ -407,3 +407,57 @@ def test_reference_fixture_people(ctx):
             else:
                 assert got["values"].tobytes() == np.ascontiguousarray(e["values"]).tobytes()
         r0 = r1
+
+
+def _message_file(n_rows, rng):
+    """configs[0]: the 40-column schema of performance/message/message.go:7-53, written like
+    performance/parquet_performance_test.go:47-55 (Write() when i % 5000 == 0, so the first row group
+    holds one row; default 1000-row pages) but uncompressed.  Pointer columns `*_0` are nil with p = 0.5,
+    the other pointer columns are never nil (:29-36)."""
+    spec = []
+    strs = {0: (3, 10), 1: (0, 5), 2: (100, 400), 3: (100, 400), 4: (20, 80), 5: (20, 80), 6: (20, 80),
+            7: (3, 10), 8: (3, 10), 9: (3, 10)}
+    for i in range(10):
+        spec.append(("col_str_%d" % i, N.BYTE_ARRAY, i % 2 == 0, strs[i]))
+    for i in range(5):
+        spec.append(("col_int_%d" % i, N.INT64, i % 2 == 0, None))
+    for i in range(5):
+        spec.append(("col_int_32_%d" % i, N.INT32, i % 2 == 0, None))
+    for i in range(5):
+        spec.append(("col_float_%d" % i, N.DOUBLE, i % 2 == 0, None))
+    for i in range(5):
+        spec.append(("col_float_32_%d" % i, N.FLOAT, i % 2 == 0, None))
+    for i in range(10):
+        spec.append(("col_bool_%d" % i, N.BOOLEAN, i % 2 == 0, None))
+    cols = [Column(name, t, [OPTIONAL if opt else REQUIRED]) for name, t, opt, _ in spec]
+    groups = [1] + [5000] * ((n_rows - 1) // 5000) + ([(n_rows - 1) % 5000] if (n_rows - 1) % 5000 else [])
+    w = ParquetWriter(cols)
+    for rows in groups:
+        w.begin_row_group()
+        for ci, (name, t, opt, sl) in enumerate(spec):
+            for p0 in range(0, rows, 1000):
+                nr = min(1000, rows - p0)
+                defs = None
+                nv = nr
+                if opt:
+                    p_nil = 0.5 if name.endswith("_0") else 0.0
+                    defs = (rng.random(nr) >= p_nil).astype(np.uint8)
+                    nv = int(defs.sum())
+                if t == N.BYTE_ARRAY:
+                    chars, offs = H.random_strings(nv, rng, sl[0], sl[1], (97, 123))
+                    w.write_page(ci, chars, defs=defs, offsets=offs)
+                else:
+                    w.write_page(ci, H.random_values(t, nv, rng), defs=defs)
+        w.end_row_group(rows)
+    buf = w.finish()
+    w.close()
+    return buf, len(groups)
+
+
+def test_performance_message_schema(ctx):
+    rng = np.random.default_rng(11)
+    buf, n_groups = _message_file(20001, rng)
+    pf = R.ParquetFile(buf)
+    assert pf.num_columns == 40 and pf.num_row_groups == n_groups and pf.row_group_rows(0) == 1
+    H.check_file(buf, ctx)            # all row groups in one batch
+    H.check_file(buf, ctx, rg_batch=1)  # one readRowGroup per call, as the reference reader does
