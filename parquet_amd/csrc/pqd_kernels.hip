@@ -255,16 +255,35 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
         }
     }
 
-    // ---- sweep 1: every start of my sub-tile learns where its chain leaves the sub-tile
+    // ---- sweep 1: every start of my sub-tile learns where its chain leaves the sub-tile.  The marking
+    // pass keeps each start's own step (next start, values, record) in registers for the replay below.
+    u32 st_nxt[MARK ? CH_SUB : 1], st_val[MARK && KIND == KIND_LEVELS ? CH_SUB : 1], st_info[MARK && KIND == KIND_LEVELS ? CH_SUB : 1];
 #pragma unroll
     for (int k = CH_SUB - 1; k >= 0; k--) {
         const u32 p = sub_lo + k;
         u32 tgt = p, c = 0, v = 0;
+        if (MARK) st_nxt[k] = ERR_POS;
         if (p < L) {
             u32 nxt;
             u64 vals = 0;
-            if (KIND == KIND_LEVELS) { u32 info; rle_step_win(win64(w, k), p, L, R.width, nxt, vals, info); }
-            else str_step_win(win32(w, k), p, L, nxt);
+            if (KIND == KIND_LEVELS) {
+                u32 info;
+                const u64 x = win64(w, k);
+                rle_step_win(x, p, L, R.width, nxt, vals, info);
+                if (MARK) {
+                    if (!(info & 1) && R.width <= 8) {
+                        // RLE run of a narrow level: the record carries the value itself (width 0: value 0)
+                        const u32 vp = info >> 1, d = vp - p;
+                        u32 val = 0;
+                        if (R.width > 0 && nxt != ERR_POS) val = d < 8 ? (u32)(x >> (8 * d)) & 0xFF : (u32)rsrc[vp];
+                        info = val << 1;
+                    }
+                    if ((info & 1) && R.width == 0) info = 0;  // width 0 bit-packed groups are runs of zeros
+                    st_val[k] = (u32)vals;
+                    st_info[k] = info;
+                }
+            } else str_step_win(win32(w, k), p, L, nxt);
+            if (MARK) st_nxt[k] = nxt;
             tgt = nxt; c = 1; v = (u32)vals;  // one run never holds more than 2^31 values
             if (nxt < sub_hi && nxt < L) {     // lands on a later start of this sub-tile: memoised
                 const u32 mi = memo_idx(nxt - tb);
@@ -352,23 +371,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
 #pragma unroll
     for (int k = 0; k < (int)CH_SUB; k++) {
         if (q == sub_lo + k && q < L) {
-            u32 nxt;
             if (KIND == KIND_LEVELS) {
-                u32 info;
-                u64 vals;
-                const u64 x = win64(w, k);
-                rle_step_win(x, q, L, R.width, nxt, vals, info);
-                if (!(info & 1) && R.width <= 8) {
-                    // RLE run of a narrow level: the record carries the value itself (width 0: value 0)
-                    const u32 vp = info >> 1, d = vp - q;
-                    u32 val = 0;
-                    if (R.width > 0 && nxt != ERR_POS) val = d < 8 ? (u32)(x >> (8 * d)) & 0xFF : (u32)rsrc[vp];
-                    info = val << 1;
-                }
-                if ((info & 1) && R.width == 0) info = 0;  // width 0 bit-packed groups are runs of zeros
+                const u64 vals = st_val[k];
                 RunRec rr;
                 rr.out_off = o < n_out ? (u32)o : (u32)n_out;
-                rr.info = info;
+                rr.info = st_info[k];
                 run_tbl[R.run_base + rank] = rr;
                 // which output tiles start inside this run
                 if (vals > 0 && o < n_out) {
@@ -377,7 +384,6 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
                 }
                 o += vals;
             } else {
-                str_step_win(win32(w, k), q, L, nxt);
                 // string `rank` of the page starts at q: its chars begin at q + 4; every earlier string of
                 // the page contributed 4 length bytes.  A page never holds more values than levels.
                 if (rank < n_out) {
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
                 }
             }
             rank++;
-            q = nxt;
+            q = st_nxt[k];
         }
     }
 }
