@@ -45,6 +45,7 @@ constexpr u32 CH_G_STRINGS = 64;  // tiles per hop group (string pages are thous
 
 constexpr u32 OT = 4096;          // level values per expand tile
 constexpr u32 EX_CAP = 1024;      // runs staged in LDS per expand batch
+constexpr u32 EX_STAGE = OT + 64;   // staged packed bytes per expand batch (OT values of <= 8 bits + slack)
 constexpr u32 BT = 4096;          // bools per tile
 constexpr u32 ST = 4096;          // string chars per gather tile
 constexpr u32 RT = 4096;          // levels per row-offset tile

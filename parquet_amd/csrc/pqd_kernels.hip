@@ -542,6 +542,9 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
     __shared__ u32 s_info[EX_CAP];
     __shared__ __attribute__((aligned(16))) unsigned short s_mark[OT];
     __shared__ u32 s_wave[4];
+    // ESZ == 1 (levels, width <= 8): the packed source bytes the tile needs, staged once per batch
+    __shared__ __attribute__((aligned(16))) u8 s_src[ESZ == 1 ? EX_STAGE : 16];
+    __shared__ u32 s_rng[2];
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 ot = blockIdx.x;
     const u32 ri = find_owner(otile_prefix, n_regions, ot);
@@ -576,7 +579,10 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
             s_out[i] = rr.out_off;
             s_info[i] = rr.info;
         }
-        if (tid == 0) s_out[m] = first + m < n_runs ? runs[first + m].out_off : n_out;
+        if (tid == 0) {
+            s_out[m] = first + m < n_runs ? runs[first + m].out_off : n_out;
+            s_rng[0] = 0xFFFFFFFFu; s_rng[1] = 0;
+        }
         // clear the marks (16 per thread)
         *(u32x4*)(s_mark + tid * 16) = u32x4{0, 0, 0, 0};
         *(u32x4*)(s_mark + tid * 16 + 8) = u32x4{0, 0, 0, 0};
@@ -587,9 +593,38 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
         for (u32 i = tid; i < m; i += 256) {
             const u32 o = s_out[i], oe = s_out[i + 1];
             const u32 start = i == 0 ? cur : o;
-            if (oe > start && start < batch_hi && start >= cur) s_mark[start - t_lo] = (unsigned short)(i + 1);
+            if (oe > start && start < batch_hi && start >= cur) {
+                s_mark[start - t_lo] = (unsigned short)(i + 1);
+                if (ESZ == 1 && (s_info[i] & 1)) {
+                    // source bytes of the groups that hold positions [start, min(oe, batch_hi))
+                    const u32 stop = oe < batch_hi ? oe : batch_hi, pay = s_info[i] >> 1;
+                    atomicMin(&s_rng[0], pay + ((start - o) >> 3) * w);
+                    atomicMax(&s_rng[1], pay + ((stop - o + 7) >> 3) * w);
+                }
+            }
         }
         __syncthreads();
+        u32 stg_lo = 0;
+        if (ESZ == 1) {
+            stg_lo = s_rng[0];
+            const u32 stg_hi = s_rng[1];
+            // at most OT values of <= 8 bits plus two partial groups: always fits EX_STAGE
+            if (stg_hi > stg_lo) {
+                for (u32 i = tid * 16; i < stg_hi - stg_lo + 2; i += 256 * 16) {
+                    const u32 p = stg_lo + i;
+                    u32x4 v = {0, 0, 0, 0};
+                    if (p < L) {
+                        if (L - p >= 16) v = *(const u32x4_u*)(rsrc + p);
+                        else {
+                            u32 t[4] = {0, 0, 0, 0};
+                            for (u32 b = 0; b < L - p; b++) t[b >> 2] |= (u32)rsrc[p + b] << (8 * (b & 3));
+                            v.x = t[0]; v.y = t[1]; v.z = t[2]; v.w = t[3];
+                        }
+                    }
+                    if (i + 16 <= EX_STAGE) *(u32x4*)(s_src + i) = v;
+                }
+            }
+        }
         // running maximum of the marks = (index + 1) of the run that owns each position
         u32 rk[16];
         {
@@ -616,6 +651,30 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
             for (int k = 0; k < 16; k++) rk[k] = rk[k] > carry ? rk[k] : carry;
         }
         // decode my positions inside [cur, batch_hi)
+        if (ESZ == 1) {
+            const u32 mask = (1u << w) - 1;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u32 pos = o0 + k;
+                if (pos >= cur && pos < batch_hi) {
+                    const u32 r = rk[k] - 1;
+                    const u32 ro = s_out[r], ri = s_info[r];
+                    u32 v = ri >> 1;  // RLE: the value
+                    if (ri & 1) {
+                        // bit-packed: value j of group g sits at bit j*w of the group's w bytes, LSB first
+                        const u32 rel = pos - ro, bit = (rel & 7) * w;
+                        const u32 b = (ri >> 1) + (rel >> 3) * w + (bit >> 3) - stg_lo;
+                        v = (((u32)s_src[b] | ((u32)s_src[b + 1] << 8)) >> (bit & 7)) & mask;
+                    }
+                    if (k < 8) acc_lo |= (u64)(v & 0xFF) << (8 * k); else acc_hi |= (u64)(v & 0xFF) << (8 * (k - 8));
+                }
+            }
+            __syncthreads();  // s_src / s_out are rewritten by the next batch
+            if (batch_hi >= t_hi) break;
+            first += m;
+            cur = batch_hi;
+            continue;
+        }
         u32 cur_r = 0, r_out = 0, r_info = 0, rle_val = 0, win_bit0 = 0;
         u64 win = 0;
         bool win_ok = false;
