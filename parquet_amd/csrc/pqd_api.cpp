@@ -17,6 +17,8 @@ using namespace pqd;
 struct pqd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // side stream of the PLAIN value gather
+    bool overlap = true;            // PQD_OVERLAP=0 keeps everything on one stream
     std::string err;
     u32 copy_grid = 0x7fffffffu;  // one block per 4 KiB tile; PQD_COPY_GRID caps it (then blocks grid-stride)
 };
@@ -83,6 +85,7 @@ struct pqd_plan {
     // ring of per-run event sets: {run start, run end, value gather start, value gather end}
     static constexpr int EV_RING = 256;
     hipEvent_t ev[EV_RING][4] = {};
+    hipEvent_t ev_fork = nullptr;  // orders the value gather's side stream after the run start
     uint64_t runs = 0;
     bool ran = false, synced = false;
     int last_status = 0;
@@ -125,12 +128,16 @@ int pqd_create(int device, pqd_ctx** out) {
     pqd_ctx* ctx = new pqd_ctx();
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) {
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return PQD_E_HIP;
     }
     const char* g = getenv("PQD_COPY_GRID");
     if (g && atoi(g) > 0) ctx->copy_grid = (u32)atoi(g);
+    const char* ov = getenv("PQD_OVERLAP");
+    if (ov) ctx->overlap = atoi(ov) != 0;
     *out = ctx;
     return PQD_OK;
 }
@@ -139,6 +146,7 @@ void pqd_destroy(pqd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
 }
 
@@ -179,6 +187,7 @@ void pqd_plan_destroy(pqd_plan* pl) {
     for (auto& set : pl->ev)
         for (hipEvent_t e : set)
             if (e) (void)hipEventDestroy(e);
+    if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
     delete pl;
 }
 
@@ -371,7 +380,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         }
         if (C.max_def > 0) {
             pl->row_chunks.push_back((u32)c);
-            push_prefix(pl->rtile_prefix, (C.n_levels + RT - 1) / RT, ovf);
+            push_prefix(pl->rtile_prefix, (C.n_levels + RT - 1) / RT, ovf);  // validity words come from these tiles too
         }
     }
     if (ovf) return fail(ctx, PQD_E_UNSUPPORTED, "batch too large for 32-bit tile indices");
@@ -524,6 +533,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& set : pl->ev)
         for (hipEvent_t& e : set) HIP_TRY(ctx, hipEventCreate(&e));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
     pl->h_chunk_dyn.resize(n_chunks);
     guard.p = nullptr;
     *out = pl;
@@ -547,10 +557,17 @@ int pqd_plan_run(pqd_plan* pl, const void* src_device) {
     HIP_TRY(ctx, hipMemsetAsync(pl->zero_begin, 0, pl->zero_bytes, st));
 
     // PLAIN fixed-width values: independent of the levels (the reference reads the concatenated
-    // values regions as one stream)
-    HIP_TRY(ctx, hipEventRecord(ev[2], st));
-    HIP_TRY(ctx, launch_copy(st, src, pl->d_segs, pl->d_seg_blk_prefix, (u32)pl->segs.size(), pl->n_copy_blocks, ctx->copy_grid));
-    HIP_TRY(ctx, hipEventRecord(ev[3], st));
+    // values regions as one stream).  The gather is HBM-bound and the level / string chains are
+    // instruction-bound, so when both exist the gather runs beside them on a second stream.
+    const bool side = ctx->overlap && pl->n_copy_blocks && (n_lreg || n_sreg);
+    hipStream_t cst = side ? ctx->stream2 : st;
+    if (side) {
+        HIP_TRY(ctx, hipEventRecord(pl->ev_fork, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(cst, pl->ev_fork, 0));
+    }
+    HIP_TRY(ctx, hipEventRecord(ev[2], cst));
+    HIP_TRY(ctx, launch_copy(cst, src, pl->d_segs, pl->d_seg_blk_prefix, (u32)pl->segs.size(), pl->n_copy_blocks, ctx->copy_grid));
+    HIP_TRY(ctx, hipEventRecord(ev[3], cst));
 
     // levels
     if (n_lreg) {
@@ -570,6 +587,7 @@ int pqd_plan_run(pqd_plan* pl, const void* src_device) {
     }
     HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
                              pl->d_row_tiles, pl->d_chunk_dyn));
+    if (side) HIP_TRY(ctx, hipStreamWaitEvent(st, ev[3], 0));
     HIP_TRY(ctx, hipEventRecord(ev[1], st));
     pl->runs++;
     pl->ran = true;
