@@ -52,6 +52,7 @@ struct pqd_plan {
     std::vector<ChunkRec> chunks;
     std::vector<PageRec> pages;
     std::vector<Region> lregions, sregions;
+    std::vector<u32> otile_region;
     std::vector<u32> ltile_prefix, lotile_prefix, stile_chain_prefix, lgroup_prefix, sgroup_prefix;
     std::vector<Seg> segs;
     std::vector<u32> seg_blk_prefix;
@@ -64,6 +65,7 @@ struct pqd_plan {
     size_t arena_bytes = 0;
     ChunkRec* d_chunks = nullptr; PageRec* d_pages = nullptr;
     Region *d_lregions = nullptr, *d_sregions = nullptr;
+    u32* d_otile_region = nullptr;
     u32 *d_ltile_prefix = nullptr, *d_lotile_prefix = nullptr, *d_stile_chain_prefix = nullptr;
     u32 *d_lgroup_prefix = nullptr, *d_sgroup_prefix = nullptr;
     Seg* d_segs = nullptr; u32* d_seg_blk_prefix = nullptr;
@@ -386,6 +388,10 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if (ovf) return fail(ctx, PQD_E_UNSUPPORTED, "batch too large for 32-bit tile indices");
     pl->n_ltiles = pl->ltile_prefix.back();
     pl->n_lotiles = pl->lotile_prefix.back();
+    pl->otile_region.reserve((size_t)pl->n_lotiles + 1);
+    for (size_t r = 0; r < pl->lregions.size(); r++)
+        pl->otile_region.insert(pl->otile_region.end(), pl->lotile_prefix[r + 1] - pl->lotile_prefix[r], (u32)r);
+    pl->otile_region.push_back(ERR_POS);  // spare entry: the tile after the last belongs to no region
     pl->n_stiles_chain = pl->stile_chain_prefix.back();
     pl->n_btiles = pl->btile_prefix.back();
     pl->n_stiles = pl->stile_prefix.back();
@@ -398,6 +404,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_sreg = ap.take(pl->sregions.size() * sizeof(Region));
     const size_t o_ltp = ap.take(pl->ltile_prefix.size() * 4);
     const size_t o_lotp = ap.take(pl->lotile_prefix.size() * 4);
+    const size_t o_otr = ap.take(pl->otile_region.size() * 4);
     const size_t o_sctp = ap.take(pl->stile_chain_prefix.size() * 4);
     const size_t o_lgp = ap.take(pl->lgroup_prefix.size() * 4);
     const size_t o_sgp = ap.take(pl->sgroup_prefix.size() * 4);
@@ -425,7 +432,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_ste = ap.take((size_t)pl->n_stiles_chain * sizeof(TileEntry));
     const size_t o_lge = ap.take((size_t)n_lgroups * sizeof(TileEntry));
     const size_t o_sge = ap.take((size_t)n_sgroups * sizeof(TileEntry));
-    const size_t o_otf = ap.take((size_t)pl->n_lotiles * 4);
+    const size_t o_otf = ap.take(((size_t)pl->n_lotiles + 1) * 4);  // one spare entry
     const size_t ff_end = ap.total;
     // reset to 0 every run
     const size_t o_zero = ap.total;
@@ -501,6 +508,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->d_chunk_dyn = (ChunkDyn*)(A + o_cdyn);
     pl->d_ltile_entry = (TileEntry*)(A + o_lte); pl->d_stile_entry = (TileEntry*)(A + o_ste);
     pl->d_otile_first = (u32*)(A + o_otf);
+    pl->d_otile_region = (u32*)(A + o_otr);
     pl->d_otile_cnt = (u32*)(A + o_otc);
     pl->d_page_dyn = (PageDyn*)(A + o_pdyn); pl->d_status = (int*)(A + o_status);
     pl->d_segs = (Seg*)(A + o_segs); pl->d_seg_blk_prefix = (u32*)(A + o_segp);
@@ -519,6 +527,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if ((rc = upload(ctx, pl->d_sregions, pl->sregions))) return rc;
     if ((rc = upload(ctx, pl->d_ltile_prefix, pl->ltile_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_lotile_prefix, pl->lotile_prefix))) return rc;
+    if ((rc = upload(ctx, pl->d_otile_region, pl->otile_region))) return rc;
     if ((rc = upload(ctx, pl->d_stile_chain_prefix, pl->stile_chain_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_lgroup_prefix, pl->lgroup_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_sgroup_prefix, pl->sgroup_prefix))) return rc;
@@ -573,7 +582,7 @@ int pqd_plan_run(pqd_plan* pl, const void* src_device) {
     if (n_lreg) {
         HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, src, pl->lchain, pl->d_runs, pl->d_otile_first, pl->d_page_dyn, pl->d_status, 0));
         HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, src, pl->lchain, pl->d_runs, pl->d_otile_first, pl->d_page_dyn, pl->d_status, 1));
-        HIP_TRY(ctx, launch_levels_expand(st, 1, src, pl->d_lregions, pl->d_lotile_prefix, n_lreg, pl->n_lotiles, pl->d_runs,
+        HIP_TRY(ctx, launch_levels_expand(st, 1, src, pl->d_lregions, pl->d_otile_region, pl->d_lotile_prefix, n_lreg, pl->n_lotiles, pl->d_runs,
                                           pl->d_otile_first, pl->d_ltotals, pl->d_otile_cnt, pl->d_page_dyn));
     }
     HIP_TRY(ctx, launch_page_scan(st, pl->d_chunks, n_chunks, pl->d_pages, n_pages, pl->d_page_dyn, pl->d_chunk_dyn, pl->d_status));
@@ -737,7 +746,7 @@ int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block_, size_t block_len
     const size_t o_ff = ap.total;
     const size_t o_te = ap.take((size_t)n_tiles * sizeof(TileEntry));
     const size_t o_ge = ap.take((size_t)n_groups * sizeof(TileEntry));
-    const size_t o_otf = ap.take((size_t)n_otiles * 4);
+    const size_t o_otf = ap.take(((size_t)n_otiles + 1) * 4);
     const size_t ff_end = ap.total;
     const size_t o_zero = ap.total;
     const size_t o_pdyn = ap.take(sizeof(PageDyn));
@@ -777,7 +786,7 @@ int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block_, size_t block_len
     HIP_TRY(ctx, hipMemcpyAsync(A + o_otp, otp2, 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, A + o_src, ca, (RunRec*)(A + o_runs), (u32*)(A + o_otf), (PageDyn*)(A + o_pdyn),
                               (int*)(A + o_status), 1));
-    HIP_TRY(ctx, launch_levels_expand(st, esz, A + o_src, (Region*)(A + o_reg), (u32*)(A + o_otp), 1, otp2[1], (RunRec*)(A + o_runs),
+    HIP_TRY(ctx, launch_levels_expand(st, esz, A + o_src, (Region*)(A + o_reg), nullptr, (u32*)(A + o_otp), 1, otp2[1], (RunRec*)(A + o_runs),
                                       (u32*)(A + o_otf), (RegionTotal*)(A + o_tot), nullptr, (PageDyn*)(A + o_pdyn)));
     HIP_TRY(ctx, hipMemcpyAsync(out_host, A + o_out, n_emit * (size_t)esz, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));

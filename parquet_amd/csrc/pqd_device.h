@@ -45,7 +45,6 @@ constexpr u32 CH_G_STRINGS = 64;  // tiles per hop group (string pages are thous
 
 constexpr u32 OT = 4096;          // level values per expand tile
 constexpr u32 EX_CAP = 1024;      // runs staged in LDS per expand batch
-constexpr u32 EX_STAGE = OT + 64;   // staged packed bytes per expand batch (OT values of <= 8 bits + slack)
 constexpr u32 BT = 4096;          // bools per tile
 constexpr u32 ST = 4096;          // string chars per gather tile
 constexpr u32 RT = 4096;          // levels per row-offset tile
@@ -114,9 +113,11 @@ struct ChainArgs {
 };
 hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs& a, RunRec* run_tbl, u32* otile_first_run,
                         const PageDyn* page_dyn, int* status, int phase);
-hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_prefix,
-                                u32 n_regions, u32 n_otiles, const RunRec* run_tbl, const u32* otile_first_run,
-                                const RegionTotal* totals, u32* otile_cnt, PageDyn* page_dyn);
+// otile_region: region of every expand tile plus one spare entry (may be null: the kernel then searches
+// otile_prefix); otile_first_run must have one spare entry after its n_otiles.
+hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_region,
+                                const u32* otile_prefix, u32 n_regions, u32 n_otiles, const RunRec* run_tbl,
+                                const u32* otile_first_run, const RegionTotal* totals, u32* otile_cnt, PageDyn* page_dyn);
 hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks, const PageRec* pages, u32 n_pages,
                             PageDyn* page_dyn, ChunkDyn* chunk_dyn, int* status);
 hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids, const u32* btile_prefix,

@@ -121,55 +121,66 @@ static __device__ __forceinline__ u32 sat_add32(u32 a, u32 b) {
 }
 static __device__ __forceinline__ u32 memo_idx(u32 rel) { return (rel % CH_SUB) * 65 + rel / CH_SUB; }
 
-// One hybrid-RLE run header at region position p (p < L), given x = the 8 bytes at p..p+7 (bytes at or
-// past L read as zero).  nxt = position of the next header (== L when the block ends), ERR_POS when the
-// reference would fail:
+// One hybrid-RLE run header at region position p (p < L), given the 8 bytes at p..p+7 as two little-endian
+// words (bytes at or past L read as zero).  nxt = position of the next header (== L when the block ends),
+// ERR_POS when the reference would fail:
 //   header = ULEB128 (readLEB128, rle.go:274-290; headers longer than 8 bytes are rejected here)
 //   even → RLE run: count = header >> 1, value in ceil(w/8) bytes (rle.go:218-244)
 //   odd  → bit-packed: groups = header >> 1, values = 8*groups, w*groups bytes; a short read is zero
 //          padded, a read at the very end of the block is io.EOF (rle.go:197-216)
 // info = (position of the value byte(s) or of the packed bytes) << 1 | bit-packed flag.
-static __device__ __forceinline__ void rle_step_win(u64 x, u32 p, u32 L, u32 w, u32& nxt, u64& vals, u32& info) {
-    nxt = ERR_POS; vals = 0; info = 0;
-    const u64 stop = ~x & 0x8080808080808080ull;
-    if (!stop) return;
-    const u32 n = ((u32)__builtin_ctzll(stop) >> 3) + 1;  // header bytes
-    if (n > L - p) return;                                // header cut off by the end of the block
-    const u64 y = x & (0x7F7F7F7F7F7F7F7Full >> (8 * (8 - n)));
-    const u64 h = (y & 0x7F) | ((y >> 1) & (0x7Full << 7)) | ((y >> 2) & (0x7Full << 14)) | ((y >> 3) & (0x7Full << 21)) |
-                  ((y >> 4) & (0x7Full << 28)) | ((y >> 5) & (0x7Full << 35)) | ((y >> 6) & (0x7Full << 42)) |
-                  ((y >> 7) & (0x7Full << 49));
+// Runs of more than 2^31 values and bit-packed runs of more than 2^28 groups are rejected, so only the
+// low 32 header bits are ever assembled; the bits above them just have to be zero (or, for an RLE run
+// of exactly 2^31 values, bit 32 alone).  Everything is 32-bit arithmetic: this is the inner loop of
+// the chain kernels.
+static __device__ __forceinline__ void rle_step_w32(u32 lo, u32 hi, u32 p, u32 L, u32 w, u32& nxt, u32& vals, u32& info) {
+    // straight-line on purpose: selects instead of early returns keep the wave out of exec-mask branches
+    const u32 slo = ~lo & 0x80808080u, shi = ~hi & 0x80808080u;
+    const bool in_lo = slo != 0;
+    const u32 s = in_lo ? slo : shi;                      // stop bit lives in this word
+    const u32 n = ((u32)__builtin_ctz(s | 0x80000000u) >> 3) + (in_lo ? 1u : 5u);  // header bytes
+    const u32 m = s ^ (s - 1);                            // every bit up to the stop byte
+    const u32 a = lo & (in_lo ? m : 0xFFFFFFFFu), b = hi & (in_lo ? 0u : m) & 0x7F7F7F7Fu;
+    bool bad = (s == 0) | (n > L - p);                    // no stop byte in 8 / header cut off by the block end
+    const u32 h = (a & 0x7F) | (((a >> 8) & 0x7F) << 7) | (((a >> 16) & 0x7F) << 14) | (((a >> 24) & 0x7F) << 21) | (b << 28);
+    const u32 above = b & 0x7F7F7F70u;                    // header bits 32 and up
     const u32 q = p + n;
-    if ((h & 1) == 0) {
-        const u64 count = h >> 1;
-        if (count > (1ull << 31)) return;
-        const u32 bw = (w + 7) >> 3;
-        if (bw > L - q) return;       // io.EOF reading the run value
-        info = q << 1;
-        nxt = q + bw;
-        vals = count;
+    const bool bp = (h & 1) != 0;
+    const u32 cnt = h >> 1;
+    // RLE run
+    const u32 bw = (w + 7) >> 3;
+    const bool rle_bad = ((above != 0) & ((above != 0x10u) | (cnt != 0))) | (bw > L - q);  // > 2^31 values / io.EOF on the value
+    const u32 rle_cnt = above ? 0x80000000u : cnt;
+    // bit-packed run
+    const bool bp_bad = (above != 0) | (cnt > (1u << 28)) | ((w != 0) & (q >= L)); // exhausted reader: io.EOF
+    u32 bp_nxt;
+    if (L < (1u << 24)) {
+        // w * groups in 24-bit arithmetic: groups beyond 2^24 - 1 overshoot the block anyway
+        const u32 prod = __umul24(w, cnt < 0xFFFFFFu ? cnt : 0xFFFFFFu);
+        bp_nxt = prod >= L - q ? L : q + prod;
     } else {
-        const u64 groups = h >> 1;
-        if (groups > (1ull << 28)) return;
-        info = (q << 1) | 1;
-        if (w == 0) { vals = groups * 8; nxt = q; return; }
-        if (q >= L) return;           // exhausted reader: io.EOF
-        vals = groups * 8;
-        const u64 e = (u64)q + (u64)w * groups;
-        nxt = e > L ? L : (u32)e;
+        const u64 e = (u64)q + (u64)w * cnt;
+        bp_nxt = e > L ? L : (u32)e;
     }
+    if (w == 0) bp_nxt = q;
+    bad = bad | (bp ? bp_bad : rle_bad);
+    nxt = bad ? ERR_POS : (bp ? bp_nxt : q + bw);
+    vals = bad ? 0u : (bp ? cnt * 8 : rle_cnt);
+    info = bad ? 0u : ((q << 1) | (bp ? 1u : 0u));
+}
+static __device__ __forceinline__ void rle_step_win(u64 x, u32 p, u32 L, u32 w, u32& nxt, u64& vals, u32& info) {
+    u32 v;
+    rle_step_w32((u32)x, (u32)(x >> 32), p, L, w, nxt, v, info);
+    vals = v;
 }
 
 // One PLAIN BYTE_ARRAY value at region position p given its 4 length bytes: int32 LE length, then the
 // bytes (template_string.go:47-58).  A negative length panics in the reference; a value running past
 // the region is reported as corrupt.
 static __device__ __forceinline__ void str_step_win(u32 len, u32 p, u32 L, u32& nxt) {
-    nxt = ERR_POS;
-    if (L - p < 4) return;
-    if (len & 0x80000000u) return;
-    const u64 e = (u64)p + 4 + len;
-    if (e > L) return;
-    nxt = (u32)e;
+    const u32 rem = L - p;  // p < L
+    const bool bad = (rem < 4) | ((len & 0x80000000u) != 0) | (len > rem - 4);
+    nxt = bad ? ERR_POS : p + 4 + len;
 }
 
 // The same steps reading their bytes one at a time (used off the fast path).
@@ -211,9 +222,19 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
                                                       const PageDyn* __restrict__ page_dyn) {
     constexpr u32 E = KIND == KIND_LEVELS ? CH_E_LEVELS : CH_E_STRINGS;
     constexpr u32 MEMO = CH_SUB * 65;
-    __shared__ u32 m_tgt[MEMO];
+    // memo per start: exit position, elements passed, and (levels) level values passed.  Levels keep
+    // {exit, values} in one 8-byte entry so that a lookup is a single LDS read.
+    __shared__ u64 m_tv[KIND == KIND_LEVELS ? MEMO : 1];
+    __shared__ u32 m_tgt[KIND == KIND_LEVELS ? 1 : MEMO];
     __shared__ unsigned short m_cnt[MEMO];
-    __shared__ u32 m_val[KIND == KIND_LEVELS ? MEMO : 1];
+    auto memo_get = [&](u32 mi, u32& tgt, u32& val) {
+        if (KIND == KIND_LEVELS) { const u64 e = m_tv[mi]; tgt = (u32)e; val = (u32)(e >> 32); }
+        else { tgt = m_tgt[mi]; val = 0; }
+    };
+    auto memo_put = [&](u32 mi, u32 tgt, u32 val) {
+        if (KIND == KIND_LEVELS) m_tv[mi] = (u64)tgt | ((u64)val << 32);
+        else m_tgt[mi] = tgt;
+    };
     __shared__ u32 e_pos[MARK ? 64 : 1], e_cnt[MARK ? 64 : 1];
     __shared__ u64 e_val[MARK ? 64 : 1];
 
@@ -261,88 +282,101 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
 #pragma unroll
     for (int k = CH_SUB - 1; k >= 0; k--) {
         const u32 p = sub_lo + k;
-        u32 tgt = p, c = 0, v = 0;
-        if (MARK) st_nxt[k] = ERR_POS;
-        if (p < L) {
-            u32 nxt;
-            u64 vals = 0;
-            if (KIND == KIND_LEVELS) {
-                u32 info;
-                const u64 x = win64(w, k);
-                rle_step_win(x, p, L, R.width, nxt, vals, info);
-                if (MARK) {
-                    if (!(info & 1) && R.width <= 8) {
-                        // RLE run of a narrow level: the record carries the value itself (width 0: value 0)
-                        const u32 vp = info >> 1, d = vp - p;
-                        u32 val = 0;
-                        if (R.width > 0 && nxt != ERR_POS) val = d < 8 ? (u32)(x >> (8 * d)) & 0xFF : (u32)rsrc[vp];
-                        info = val << 1;
-                    }
-                    if ((info & 1) && R.width == 0) info = 0;  // width 0 bit-packed groups are runs of zeros
-                    st_val[k] = (u32)vals;
-                    st_info[k] = info;
+        const bool valid = p < L;
+        u32 nxt, vals = 0;
+        if (KIND == KIND_LEVELS) {
+            u32 info;
+            const u32 xlo = win32(w, k), xhi = win32(w, k + 4);
+            rle_step_w32(xlo, xhi, p, L, R.width, nxt, vals, info);
+            if (MARK) {
+                if (!(info & 1) && R.width <= 8) {
+                    // RLE run of a narrow level: the record carries the value itself (width 0: value 0)
+                    const u32 vp = info >> 1, d = vp - p;
+                    u32 val = 0;
+                    if (R.width > 0 && nxt != ERR_POS)
+                        val = d < 4 ? (xlo >> (8 * d)) & 0xFF : d < 8 ? (xhi >> (8 * (d - 4))) & 0xFF : (u32)rsrc[vp];
+                    info = val << 1;
                 }
-            } else str_step_win(win32(w, k), p, L, nxt);
-            if (MARK) st_nxt[k] = nxt;
-            tgt = nxt; c = 1; v = (u32)vals;  // one run never holds more than 2^31 values
-            if (nxt < sub_hi && nxt < L) {     // lands on a later start of this sub-tile: memoised
-                const u32 mi = memo_idx(nxt - tb);
-                tgt = m_tgt[mi];
-                c += m_cnt[mi];
-                if (KIND == KIND_LEVELS) v = sat_add32(v, m_val[mi]);
+                if ((info & 1) && R.width == 0) info = 0;  // width 0 bit-packed groups are runs of zeros
+                st_val[k] = vals;
+                st_info[k] = info;
             }
-        }
-        const u32 mi = memo_idx(p - tb);
-        m_tgt[mi] = tgt;
+        } else str_step_win(win32(w, k), p, L, nxt);
+        if (!valid) nxt = ERR_POS;
+        if (MARK) st_nxt[k] = nxt;
+        // a step that lands on a later start of this sub-tile takes over that start's memoised answer
+        // (the lookup is unconditional: lanes without one read their own slot and drop the result)
+        const u32 mi = (u32)k * 65 + lane;
+        const bool in = (nxt < sub_hi) & (nxt < L);
+        const u32 mj = in ? (nxt - sub_lo) * 65 + lane : mi;
+        u32 t2, v2;
+        memo_get(mj, t2, v2);
+        const u32 c2 = m_cnt[mj];
+        u32 tgt = in ? t2 : nxt;
+        u32 c = in ? c2 + 1 : 1;                      // one run never holds more than 2^31 values
+        u32 v = in ? sat_add32(vals, v2) : vals;
+        if (!valid) { tgt = p; c = 0; v = 0; }
+        memo_put(mi, tgt, v);
         m_cnt[mi] = (unsigned short)c;
-        if (KIND == KIND_LEVELS) m_val[mi] = v;
     }
     __syncthreads();
 
     if (!MARK) {
-        // ---- sweep 2: sub-tile exits -> tile exits, in two levels of 8 (groups of 8 sub-tiles = 256 bytes).
-        // A start whose chain lands on a later start takes over that start's already final answer.
-        // Level A: inside every group, sub-tiles from last to first (all 8 groups at once, 4 starts per lane).
+        // ---- sweep 2, level A: sub-tile exits -> exits of groups of 8 sub-tiles (256 bytes).  Inside every
+        // group, sub-tiles from last to first (all 8 groups at once, 4 starts per lane): a start whose
+        // chain lands on a later start of its group takes over that start's already final answer.
         for (int j = 6; j >= 0; j--) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const u32 g = 2 * i + (lane >> 5), k = lane & 31;
                 const u32 rel = (g * 8 + (u32)j) * CH_SUB + k;
-                const u32 mi = memo_idx(rel);
-                const u32 t = m_tgt[mi];
+                const u32 mi = k * 65 + g * 8 + (u32)j;
+                u32 t, v;
+                memo_get(mi, t, v);
                 if (tb + rel < L && t < tb + (g + 1) * 8 * CH_SUB && t < L) {
                     const u32 mj = memo_idx(t - tb);
-                    m_tgt[mi] = m_tgt[mj];
+                    u32 t2, v2;
+                    memo_get(mj, t2, v2);
+                    memo_put(mi, t2, sat_add32(v, v2));
                     m_cnt[mi] = (unsigned short)(m_cnt[mi] + m_cnt[mj]);
-                    if (KIND == KIND_LEVELS) m_val[mi] = sat_add32(m_val[mi], m_val[mj]);
                 }
             }
             __syncthreads();
         }
-        // Level B: groups from last to first (256 starts per stage, 4 per lane).
-        for (int g = 6; g >= 0; g--) {
+        // ---- level B: only the first E starts of the tile need their tile exit; each hops from group to
+        // group (at most 7 hops) through the level-A answers and goes to the exit table.
+        constexpr int PER = E / 64;
+        u32 ht[PER], hc[PER], hv[PER];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const u32 rel = (u32)g * 8 * CH_SUB + (2 * i + (lane >> 5)) * CH_SUB + (lane & 31);
-                const u32 mi = memo_idx(rel);
-                const u32 t = m_tgt[mi];
-                if (tb + rel < L && t < te && t < L) {
-                    const u32 mj = memo_idx(t - tb);
-                    m_tgt[mi] = m_tgt[mj];
-                    m_cnt[mi] = (unsigned short)(m_cnt[mi] + m_cnt[mj]);
-                    if (KIND == KIND_LEVELS) m_val[mi] = sat_add32(m_val[mi], m_val[mj]);
+        for (int i = 0; i < PER; i++) {
+            const u32 rel = (u32)i * 64 + lane;  // E <= 256: all inside group 0
+            const u32 mi = memo_idx(rel);
+            memo_get(mi, ht[i], hv[i]);
+            hc[i] = m_cnt[mi];
+        }
+        for (int hop = 0; hop < 7; hop++) {
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                if (ht[i] < te && ht[i] < L) {
+                    const u32 mj = memo_idx(ht[i] - tb);
+                    u32 t2, v2;
+                    memo_get(mj, t2, v2);
+                    hc[i] += m_cnt[mj];
+                    hv[i] = sat_add32(hv[i], v2);
+                    ht[i] = t2;
+                    any = true;
                 }
             }
-            __syncthreads();
+            if (!__any(any)) break;
         }
-        // exit table: where the chain started at each of the first E positions leaves the tile
-        for (u32 i = lane; i < E; i += 64) {
-            const u32 mi = memo_idx(i);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
             ExitRec x;
-            x.tgt = m_tgt[mi];
-            x.cnt = m_cnt[mi];
-            x.vals = KIND == KIND_LEVELS ? m_val[mi] : 0;
-            exit_tbl[(u64)tile * E + i] = x;
+            x.tgt = ht[i];
+            x.cnt = hc[i];
+            x.vals = KIND == KIND_LEVELS ? hv[i] : 0;
+            exit_tbl[(u64)tile * E + (u32)i * 64 + lane] = x;
         }
         return;
     }
@@ -354,9 +388,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
         while (q < te && q < L) {
             const u32 rel = q - tb, sidx = rel / CH_SUB, mi = memo_idx(rel);
             e_pos[sidx] = q; e_cnt[sidx] = c; e_val[sidx] = v;
+            u32 t2, v2;
+            memo_get(mi, t2, v2);
             c += m_cnt[mi];
-            if (KIND == KIND_LEVELS) v += m_val[mi];
-            q = m_tgt[mi];
+            v += v2;
+            q = t2;
         }
     }
     __syncthreads();
@@ -364,32 +400,35 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
     u32 q = e_pos[lane];
     if (q == ERR_POS) return;
     u32 rank = e_cnt[lane];  // index of the element within the region
-    u64 o = e_val[lane];     // levels: index of the run's first level value
-    const u64 n_out = R.n_out;
-    PageDyn pd = {};
-    if (KIND == KIND_STRINGS) pd = page_dyn[R.page];
+    // levels: index of the run's first level value, clamped to the page's value count (32-bit from here on)
+    const u32 n_out = (u32)R.n_out;
+    u32 o = e_val[lane] < n_out ? (u32)e_val[lane] : n_out;
+    RunRec* const runs = run_tbl + R.run_base;
+    u32* const ofr = otile_first_run + R.otile_base;
+    int32_t* offs = nullptr;
+    u32 cbase = 0;
+    if (KIND == KIND_STRINGS) {
+        const PageDyn pd = page_dyn[R.page];
+        offs = (int32_t*)R.out + pd.val_off;
+        cbase = (u32)pd.char_off;  // offsets are int32: a chunk holds less than 2^31 chars
+    }
 #pragma unroll
     for (int k = 0; k < (int)CH_SUB; k++) {
         if (q == sub_lo + k && q < L) {
             if (KIND == KIND_LEVELS) {
-                const u64 vals = st_val[k];
+                const u32 vals = st_val[k];
                 RunRec rr;
-                rr.out_off = o < n_out ? (u32)o : (u32)n_out;
+                rr.out_off = o;
                 rr.info = st_info[k];
-                run_tbl[R.run_base + rank] = rr;
+                runs[rank] = rr;
+                const u32 oe = vals < n_out - o ? o + vals : n_out;
                 // which output tiles start inside this run
-                if (vals > 0 && o < n_out) {
-                    const u64 oe = o + vals < n_out ? o + vals : n_out;
-                    for (u64 t = (o + OT - 1) / OT; t * OT < oe; t++) otile_first_run[R.otile_base + t] = rank;
-                }
-                o += vals;
+                for (u32 t = (o + OT - 1) / OT; t * OT < oe; t++) ofr[t] = rank;
+                o = oe;
             } else {
                 // string `rank` of the page starts at q: its chars begin at q + 4; every earlier string of
                 // the page contributed 4 length bytes.  A page never holds more values than levels.
-                if (rank < n_out) {
-                    int32_t* offsets = (int32_t*)R.out;
-                    offsets[pd.val_off + rank] = (int32_t)(pd.char_off + (u64)q - 4ull * rank);
-                }
+                if (rank < n_out) offs[rank] = (int32_t)(cbase + q - 4u * rank);
             }
             rank++;
             q = st_nxt[k];
@@ -533,6 +572,181 @@ static __device__ __forceinline__ u64 load_u64_guarded(const u8* p, u32 pos, u32
     return v;
 }
 
+static __device__ __forceinline__ u32x4 load_u128_guarded(const u8* p, u32 pos, u32 L) {
+    if (pos < L && L - pos >= 16) return *(const u32x4_u*)(p + pos);
+    u32 t[4] = {0, 0, 0, 0};
+    for (u32 k = 0; k < 16; k++) if (pos + k < L) t[k >> 2] |= (u32)p[pos + k] << (8 * (k & 3));
+    return u32x4{t[0], t[1], t[2], t[3]};
+}
+
+// 16 consecutive values (one per result byte) of a bit-packed run of W-bit levels, starting at value rel0
+// of the run whose packed bytes begin at region position pay (bitpack.Unpack, bitpack.go:76-141: value j of
+// a group of 8 sits at bit j*W of the group's W bytes, LSB first; a short read is zero padded, rle.go:203-213).
+// 16 values take at most 7 + 16*W <= 128 bits from their first byte, so one 16-byte load covers them.
+template <int W>
+static __device__ __forceinline__ u32x4 unpack16(const u8* rsrc, u32 L, u32 pay, u32 rel0) {
+    const u32 bit = (rel0 & 7) * W;
+    u32x4 x = load_u128_guarded(rsrc, pay + (rel0 >> 3) * W + (bit >> 3), L);
+    if (W == 8) return x;
+    const u32 sh = bit & 7;
+    u32 d[5];
+    d[0] = __builtin_amdgcn_alignbit(x.y, x.x, sh);
+    d[1] = __builtin_amdgcn_alignbit(x.z, x.y, sh);
+    d[2] = __builtin_amdgcn_alignbit(x.w, x.z, sh);
+    d[3] = x.w >> sh;
+    d[4] = 0;
+    u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int b = k * W, q = b >> 5, r = b & 31;
+        u32 v;
+        if (r + W <= 32) v = (d[q] >> r) & ((1u << W) - 1);
+        else v = __builtin_amdgcn_alignbit(d[q + 1], d[q], r) & ((1u << W) - 1);
+        o[k >> 2] |= v << (8 * (k & 3));
+    }
+    return u32x4{o[0], o[1], o[2], o[3]};
+}
+// 16 values from position `from` on of the run (out_off, info), width w <= 8
+static __device__ __forceinline__ u32x4 run16(const u8* rsrc, u32 L, u32 w, u32 out_off, u32 info, u32 from) {
+    if (!(info & 1)) {
+        const u32 v = (info >> 1) * 0x01010101u;  // RLE: the record carries the value
+        return u32x4{v, v, v, v};
+    }
+    const u32 pay = info >> 1, rel0 = from - out_off;
+    switch (w) {
+    case 1: return unpack16<1>(rsrc, L, pay, rel0);
+    case 2: return unpack16<2>(rsrc, L, pay, rel0);
+    case 3: return unpack16<3>(rsrc, L, pay, rel0);
+    case 4: return unpack16<4>(rsrc, L, pay, rel0);
+    case 5: return unpack16<5>(rsrc, L, pay, rel0);
+    case 6: return unpack16<6>(rsrc, L, pay, rel0);
+    case 7: return unpack16<7>(rsrc, L, pay, rel0);
+    default: return unpack16<8>(rsrc, L, pay, rel0);
+    }
+}
+
+// Bytes k0.. of the 16-byte accumulator (lo, hi) are replaced by the leading bytes of v.
+static __device__ __forceinline__ void merge16(u64& lo, u64& hi, const u32x4 v, u32 k0) {
+    const u64 vlo = v.x | ((u64)v.y << 32), vhi = v.z | ((u64)v.w << 32);
+    if (k0 == 0) { lo = vlo; hi = vhi; }
+    else if (k0 < 8) {
+        const u32 sh = 8 * k0;
+        lo = (lo & ((1ull << sh) - 1)) | (vlo << sh);
+        hi = (vhi << sh) | (vlo >> (64 - sh));
+    } else {
+        const u32 sh = 8 * (k0 - 8);
+        hi = (hi & ((1ull << sh) - 1)) | (vlo << sh);
+    }
+}
+
+// =====================================================================================
+// k_levels_expand8 — the u8 level expand of the page decoder (widths 0..8).  One block per OT level
+// values of one page, one thread per 16 of them.  The runs that overlap the tile are staged in LDS;
+// a thread finds the run that owns its first position by binary search and then decodes run by run:
+// 16 values at a time straight from the page bytes, later runs overwriting the tail of the 16-byte
+// accumulator.  Real encoders emit runs of at least 8 values, so a thread touches at most 3 runs.
+// Also counts def == max_def per tile (valsFromDefs, fields.go:220-228).
+// otile_region[ot] = region of tile ot, with one spare entry; otile_first_run has one spare entry too.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_levels_expand8(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                                                        const u32* __restrict__ otile_region,
+                                                        const u32* __restrict__ otile_prefix, u32 n_regions,
+                                                        const RunRec* __restrict__ run_tbl,
+                                                        const u32* __restrict__ otile_first_run,
+                                                        const RegionTotal* __restrict__ totals, u32* __restrict__ otile_cnt) {
+    __shared__ u32 s_out[EX_CAP + 1];
+    __shared__ u32 s_info[EX_CAP];
+    __shared__ u32 s_wave[4];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 ot = blockIdx.x;
+    // independent loads first: they overlap instead of forming a chain
+    u32 first = otile_first_run[ot];
+    const u32 nf = otile_first_run[ot + 1];
+    u32 ri;
+    bool next_same;
+    if (otile_region) { ri = otile_region[ot]; next_same = otile_region[ot + 1] == ri; }
+    else { ri = find_owner(otile_prefix, n_regions, ot); next_same = ot + 1 < otile_prefix[ri + 1]; }
+    const Region R = regions[ri];
+    const RegionTotal T = totals[ri];
+    const u32 L = R.len, w = R.width;
+    const u8* rsrc = src_base + R.src_off;
+    const u32 n_out = (u32)R.n_out;
+    const u32 t_lo = (ot - R.otile_base) * OT;
+    const u32 t_hi = t_lo + OT < n_out ? t_lo + OT : n_out;
+    if (first == ERR_POS || T.err) return;  // short or corrupt block: status already set
+    const RunRec* runs = run_tbl + R.run_base;
+    // the runs this tile needs end with the run that owns the first value of the next tile
+    u32 last = T.cnt;  // exclusive
+    if (next_same && nf != ERR_POS && nf + 1 < last) last = nf + 1;
+
+    const u32 o0 = t_lo + tid * 16;  // this thread's 16 values
+    u64 acc_lo = 0, acc_hi = 0;
+    u32 cur = t_lo;                  // everything below `cur` is done
+    for (;;) {
+        // stage up to EX_CAP runs starting at `first`; they cover [cur, batch_hi)
+        const u32 m = last - first < EX_CAP ? last - first : EX_CAP;
+        if (m == 0) break;
+        for (u32 i = tid; i < m; i += 256) {
+            const RunRec rr = runs[first + i];
+            s_out[i] = rr.out_off;
+            s_info[i] = rr.info;
+        }
+        if (tid == 0) s_out[m] = first + m < T.cnt ? runs[first + m].out_off : n_out;
+        __syncthreads();
+        const u32 batch_hi = s_out[m] < t_hi ? s_out[m] : t_hi;
+        const u32 lo = o0 > cur ? o0 : cur, hi = o0 + 16 < batch_hi ? o0 + 16 : batch_hi;
+        if (lo < hi) {
+            // last staged run that starts at or before lo (run 0 starts at or before cur); among runs
+            // with equal starts this picks the last, the only one that can hold values
+            u32 a = 0, b = m;
+            while (b - a > 1) {
+                const u32 mid = (a + b) >> 1;
+                if (s_out[mid] <= lo) a = mid; else b = mid;
+            }
+            u32 r = a;
+            do {
+                const u32 so = s_out[r], se = s_out[r + 1];
+                const u32 start = so > lo ? so : lo;
+                if (se > start) merge16(acc_lo, acc_hi, run16(rsrc, L, w, so, s_info[r], start), start - o0);
+                r++;
+            } while (r < m && s_out[r] < hi);
+        }
+        if (batch_hi >= t_hi) break;
+        // next batch starts with the run that owns position batch_hi
+        first += m;
+        cur = batch_hi;
+        __syncthreads();  // the staged runs are rewritten
+    }
+
+    // store + count
+    u32 n_mine = 0;
+    if (o0 < t_hi) n_mine = t_hi - o0 < 16 ? t_hi - o0 : 16;
+    u8* dst = R.out + o0;
+    if (n_mine == 16 && (((u64)dst) & 15) == 0) {
+        u32x4 v;
+        v.x = (u32)acc_lo; v.y = (u32)(acc_lo >> 32); v.z = (u32)acc_hi; v.w = (u32)(acc_hi >> 32);
+        *(u32x4*)dst = v;
+    } else {
+        for (u32 k = 0; k < n_mine; k++) dst[k] = (u8)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8)));
+    }
+    if (R.count_level != ERR_POS) {
+        // bytes equal to count_level: XOR, then detect zero bytes
+        const u64 cl = (u64)(R.count_level & 0xFF) * 0x0101010101010101ull;
+        const u64 keep_lo = n_mine >= 8 ? ~0ull : (n_mine ? (1ull << (8 * n_mine)) - 1 : 0);
+        const u64 keep_hi = n_mine >= 16 ? ~0ull : (n_mine > 8 ? (1ull << (8 * (n_mine - 8))) - 1 : 0);
+        auto zero_bytes = [](u64 x) {  // 0x80 in every byte of x that is zero
+            return ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) & 0x8080808080808080ull;
+        };
+        u32 c = __popcll(zero_bytes(acc_lo ^ cl) & keep_lo) + __popcll(zero_bytes(acc_hi ^ cl) & keep_hi);
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+        // one count per tile, summed per page by k_page_nn (no same-address atomics)
+        if (lane == 0) s_wave[wv] = c;
+        __syncthreads();
+        if (tid == 0) otile_cnt[ot] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    }
+}
+
+// The wide variant (u16 / u32 results, widths up to 32) behind the standalone level decode.
 template <int ESZ>
 __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                        const u32* __restrict__ otile_prefix, u32 n_regions,
@@ -542,9 +756,6 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
     __shared__ u32 s_info[EX_CAP];
     __shared__ __attribute__((aligned(16))) unsigned short s_mark[OT];
     __shared__ u32 s_wave[4];
-    // ESZ == 1 (levels, width <= 8): the packed source bytes the tile needs, staged once per batch
-    __shared__ __attribute__((aligned(16))) u8 s_src[ESZ == 1 ? EX_STAGE : 16];
-    __shared__ u32 s_rng[2];
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 ot = blockIdx.x;
     const u32 ri = find_owner(otile_prefix, n_regions, ot);
@@ -579,10 +790,7 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
             s_out[i] = rr.out_off;
             s_info[i] = rr.info;
         }
-        if (tid == 0) {
-            s_out[m] = first + m < n_runs ? runs[first + m].out_off : n_out;
-            s_rng[0] = 0xFFFFFFFFu; s_rng[1] = 0;
-        }
+        if (tid == 0) s_out[m] = first + m < n_runs ? runs[first + m].out_off : n_out;
         // clear the marks (16 per thread)
         *(u32x4*)(s_mark + tid * 16) = u32x4{0, 0, 0, 0};
         *(u32x4*)(s_mark + tid * 16 + 8) = u32x4{0, 0, 0, 0};
@@ -593,38 +801,9 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
         for (u32 i = tid; i < m; i += 256) {
             const u32 o = s_out[i], oe = s_out[i + 1];
             const u32 start = i == 0 ? cur : o;
-            if (oe > start && start < batch_hi && start >= cur) {
-                s_mark[start - t_lo] = (unsigned short)(i + 1);
-                if (ESZ == 1 && (s_info[i] & 1)) {
-                    // source bytes of the groups that hold positions [start, min(oe, batch_hi))
-                    const u32 stop = oe < batch_hi ? oe : batch_hi, pay = s_info[i] >> 1;
-                    atomicMin(&s_rng[0], pay + ((start - o) >> 3) * w);
-                    atomicMax(&s_rng[1], pay + ((stop - o + 7) >> 3) * w);
-                }
-            }
+            if (oe > start && start < batch_hi && start >= cur) s_mark[start - t_lo] = (unsigned short)(i + 1);
         }
         __syncthreads();
-        u32 stg_lo = 0;
-        if (ESZ == 1) {
-            stg_lo = s_rng[0];
-            const u32 stg_hi = s_rng[1];
-            // at most OT values of <= 8 bits plus two partial groups: always fits EX_STAGE
-            if (stg_hi > stg_lo) {
-                for (u32 i = tid * 16; i < stg_hi - stg_lo + 2; i += 256 * 16) {
-                    const u32 p = stg_lo + i;
-                    u32x4 v = {0, 0, 0, 0};
-                    if (p < L) {
-                        if (L - p >= 16) v = *(const u32x4_u*)(rsrc + p);
-                        else {
-                            u32 t[4] = {0, 0, 0, 0};
-                            for (u32 b = 0; b < L - p; b++) t[b >> 2] |= (u32)rsrc[p + b] << (8 * (b & 3));
-                            v.x = t[0]; v.y = t[1]; v.z = t[2]; v.w = t[3];
-                        }
-                    }
-                    if (i + 16 <= EX_STAGE) *(u32x4*)(s_src + i) = v;
-                }
-            }
-        }
         // running maximum of the marks = (index + 1) of the run that owns each position
         u32 rk[16];
         {
@@ -651,30 +830,6 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
             for (int k = 0; k < 16; k++) rk[k] = rk[k] > carry ? rk[k] : carry;
         }
         // decode my positions inside [cur, batch_hi)
-        if (ESZ == 1) {
-            const u32 mask = (1u << w) - 1;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const u32 pos = o0 + k;
-                if (pos >= cur && pos < batch_hi) {
-                    const u32 r = rk[k] - 1;
-                    const u32 ro = s_out[r], ri = s_info[r];
-                    u32 v = ri >> 1;  // RLE: the value
-                    if (ri & 1) {
-                        // bit-packed: value j of group g sits at bit j*w of the group's w bytes, LSB first
-                        const u32 rel = pos - ro, bit = (rel & 7) * w;
-                        const u32 b = (ri >> 1) + (rel >> 3) * w + (bit >> 3) - stg_lo;
-                        v = (((u32)s_src[b] | ((u32)s_src[b + 1] << 8)) >> (bit & 7)) & mask;
-                    }
-                    if (k < 8) acc_lo |= (u64)(v & 0xFF) << (8 * k); else acc_hi |= (u64)(v & 0xFF) << (8 * (k - 8));
-                }
-            }
-            __syncthreads();  // s_src / s_out are rewritten by the next batch
-            if (batch_hi >= t_hi) break;
-            first += m;
-            cur = batch_hi;
-            continue;
-        }
         u32 cur_r = 0, r_out = 0, r_info = 0, rle_val = 0, win_bit0 = 0;
         u64 win = 0;
         bool win_ok = false;
@@ -1095,13 +1250,13 @@ hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs
                                : launch_chain_t<KIND_STRINGS>(st, src, a, run_tbl, otile_first_run, page_dyn, status, phase);
 }
 
-hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_prefix,
-                                u32 n_regions, u32 n_otiles, const RunRec* run_tbl, const u32* otile_first_run,
-                                const RegionTotal* totals, u32* otile_cnt, PageDyn* page_dyn) {
+hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_region,
+                                const u32* otile_prefix, u32 n_regions, u32 n_otiles, const RunRec* run_tbl,
+                                const u32* otile_first_run, const RegionTotal* totals, u32* otile_cnt, PageDyn* page_dyn) {
     if (n_otiles == 0) return hipSuccess;
     if (esz == 1)
-        hipLaunchKernelGGL((k_levels_expand<1>), dim3(n_otiles), dim3(256), 0, st, src, regions, otile_prefix, n_regions, run_tbl,
-                           otile_first_run, totals, otile_cnt);
+        hipLaunchKernelGGL(k_levels_expand8, dim3(n_otiles), dim3(256), 0, st, src, regions, otile_region, otile_prefix, n_regions,
+                           run_tbl, otile_first_run, totals, otile_cnt);
     else if (esz == 2)
         hipLaunchKernelGGL((k_levels_expand<2>), dim3(n_otiles), dim3(256), 0, st, src, regions, otile_prefix, n_regions, run_tbl,
                            otile_first_run, totals, otile_cnt);
