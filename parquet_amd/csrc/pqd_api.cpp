@@ -56,7 +56,7 @@ struct pqd_plan {
     std::vector<u32> ltile_prefix, lotile_prefix, stile_chain_prefix, lgroup_prefix, sgroup_prefix;
     std::vector<Seg> segs;
     std::vector<u32> seg_blk_prefix;
-    std::vector<u32> bool_pages, btile_prefix, str_pages, stile_prefix, row_chunks, rtile_prefix;
+    std::vector<u32> bool_pages, btile_prefix, row_chunks, rtile_prefix;
     std::vector<OutPtrs> outs;
     std::vector<int> chunk_width;
 
@@ -69,7 +69,7 @@ struct pqd_plan {
     u32 *d_ltile_prefix = nullptr, *d_lotile_prefix = nullptr, *d_stile_chain_prefix = nullptr;
     u32 *d_lgroup_prefix = nullptr, *d_sgroup_prefix = nullptr;
     Seg* d_segs = nullptr; u32* d_seg_blk_prefix = nullptr;
-    u32 *d_bool_pages = nullptr, *d_btile_prefix = nullptr, *d_str_pages = nullptr, *d_stile_prefix = nullptr;
+    u32 *d_bool_pages = nullptr, *d_btile_prefix = nullptr;
     u32 *d_row_chunks = nullptr, *d_rtile_prefix = nullptr;
     ExitRec *d_lexit = nullptr, *d_sexit = nullptr, *d_lgexit = nullptr, *d_sgexit = nullptr;
     TileEntry *d_ltile_entry = nullptr, *d_stile_entry = nullptr, *d_lgroup_entry = nullptr, *d_sgroup_entry = nullptr;
@@ -81,7 +81,7 @@ struct pqd_plan {
     u8 *ff_begin = nullptr, *zero_begin = nullptr;  // per-run reset ranges
     size_t ff_bytes = 0, zero_bytes = 0;
 
-    u32 n_ltiles = 0, n_lotiles = 0, n_stiles_chain = 0, n_btiles = 0, n_stiles = 0, n_rtiles = 0, n_copy_blocks = 0;
+    u32 n_ltiles = 0, n_lotiles = 0, n_stiles_chain = 0, n_btiles = 0, n_rtiles = 0, n_copy_blocks = 0;
     int64_t bytes_in = 0, copy_bytes = 0;
 
     // ring of per-run event sets: {run start, run end, value gather start, value gather end}
@@ -322,7 +322,6 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->lgroup_prefix.push_back(0);
     pl->sgroup_prefix.push_back(0);
     pl->btile_prefix.push_back(0);
-    pl->stile_prefix.push_back(0);
     pl->rtile_prefix.push_back(0);
     pl->seg_blk_prefix.push_back(0);
     auto push_prefix = [&](std::vector<u32>& v, u64 add, bool& ovf) {
@@ -373,8 +372,6 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                 pl->sregions.push_back(R);
                 push_prefix(pl->stile_chain_prefix, ((u64)P.val_len + CH_T - 1) / CH_T, ovf);
                 push_prefix(pl->sgroup_prefix, ((u64)P.val_len + CH_G_STRINGS * CH_T - 1) / (CH_G_STRINGS * CH_T), ovf);
-                pl->str_pages.push_back(pi);
-                push_prefix(pl->stile_prefix, ((u64)P.val_len + ST - 1) / ST, ovf);
             } else if (C.phys_type == PQD_BOOLEAN) {
                 pl->bool_pages.push_back(pi);
                 push_prefix(pl->btile_prefix, ((u64)P.num_values + BT - 1) / BT, ovf);
@@ -394,7 +391,6 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->otile_region.push_back(ERR_POS);  // spare entry: the tile after the last belongs to no region
     pl->n_stiles_chain = pl->stile_chain_prefix.back();
     pl->n_btiles = pl->btile_prefix.back();
-    pl->n_stiles = pl->stile_prefix.back();
     pl->n_rtiles = pl->rtile_prefix.back();
 
     // static tables
@@ -410,8 +406,6 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_sgp = ap.take(pl->sgroup_prefix.size() * 4);
     const size_t o_bp = ap.take(pl->bool_pages.size() * 4);
     const size_t o_btp = ap.take(pl->btile_prefix.size() * 4);
-    const size_t o_sp = ap.take(pl->str_pages.size() * 4);
-    const size_t o_stp = ap.take(pl->stile_prefix.size() * 4);
     const size_t o_rc = ap.take(pl->row_chunks.size() * 4);
     const size_t o_rtp = ap.take(pl->rtile_prefix.size() * 4);
     // scratch
@@ -468,7 +462,10 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         const u64 lo = (u64)(uintptr_t)R.out;
         R.out = (R.count_level == ERR_POS ? C.reps : C.defs) + lo;
     }
-    for (Region& R : pl->sregions) R.out = pl->chunks[pl->pages[R.page].chunk].offsets;
+    for (Region& R : pl->sregions) {
+        R.out = pl->chunks[pl->pages[R.page].chunk].offsets;
+        R.out2 = pl->chunks[pl->pages[R.page].chunk].chars;
+    }
 
     // PLAIN value segments: the concatenation of the pages' values regions (fields.go:131,313)
     for (size_t c = 0; c < n_chunks; c++) {
@@ -500,7 +497,6 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->d_lgexit = (ExitRec*)(A + o_lgexit); pl->d_sgexit = (ExitRec*)(A + o_sgexit);
     pl->d_lgroup_entry = (TileEntry*)(A + o_lge); pl->d_sgroup_entry = (TileEntry*)(A + o_sge);
     pl->d_bool_pages = (u32*)(A + o_bp); pl->d_btile_prefix = (u32*)(A + o_btp);
-    pl->d_str_pages = (u32*)(A + o_sp); pl->d_stile_prefix = (u32*)(A + o_stp);
     pl->d_row_chunks = (u32*)(A + o_rc); pl->d_rtile_prefix = (u32*)(A + o_rtp);
     pl->d_lexit = (ExitRec*)(A + o_lexit); pl->d_sexit = (ExitRec*)(A + o_sexit);
     pl->d_ltotals = (RegionTotal*)(A + o_ltot); pl->d_stotals = (RegionTotal*)(A + o_stot);
@@ -533,8 +529,6 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if ((rc = upload(ctx, pl->d_sgroup_prefix, pl->sgroup_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_bool_pages, pl->bool_pages))) return rc;
     if ((rc = upload(ctx, pl->d_btile_prefix, pl->btile_prefix))) return rc;
-    if ((rc = upload(ctx, pl->d_str_pages, pl->str_pages))) return rc;
-    if ((rc = upload(ctx, pl->d_stile_prefix, pl->stile_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_row_chunks, pl->row_chunks))) return rc;
     if ((rc = upload(ctx, pl->d_rtile_prefix, pl->rtile_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_segs, pl->segs))) return rc;
@@ -591,8 +585,7 @@ int pqd_plan_run(pqd_plan* pl, const void* src_device) {
     if (n_sreg) {
         HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 0));
         HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 1));
-        HIP_TRY(ctx, launch_str_gather(st, src, pl->d_pages, pl->d_str_pages, pl->d_stile_prefix, (u32)pl->str_pages.size(),
-                                       pl->n_stiles, pl->d_chunks, pl->d_page_dyn, pl->d_sregions, n_sreg, pl->d_stotals, pl->d_status));
+        HIP_TRY(ctx, launch_str_check(st, pl->d_pages, pl->d_chunks, pl->d_page_dyn, pl->d_sregions, n_sreg, pl->d_stotals, pl->d_status));
     }
     HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
                              pl->d_row_tiles, pl->d_chunk_dyn));

@@ -46,7 +46,6 @@ constexpr u32 CH_G_STRINGS = 64;  // tiles per hop group (string pages are thous
 constexpr u32 OT = 4096;          // level values per expand tile
 constexpr u32 EX_CAP = 1024;      // runs staged in LDS per expand batch
 constexpr u32 BT = 4096;          // bools per tile
-constexpr u32 ST = 4096;          // string chars per gather tile
 constexpr u32 RT = 4096;          // levels per row-offset tile
 
 struct Region {
@@ -58,6 +57,7 @@ struct Region {
     u64 run_base;    // first entry of the region in the run table (levels)
     u64 n_out;       // levels: values to emit (page num_values); strings: upper bound of values in the page
     u8* out;         // levels: destination of value 0; strings: the chunk's offsets array
+    u8* out2;        // strings: the chunk's chars array
     u32 page;        // page index
     u32 count_level; // levels: count values equal to this into page_dyn[page].nn; ERR_POS = do not count
     u32 group_base;  // first hop group of the region in the global group numbering
@@ -122,10 +122,8 @@ hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks
                             PageDyn* page_dyn, ChunkDyn* chunk_dyn, int* status);
 hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids, const u32* btile_prefix,
                         u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn);
-hipError_t launch_str_gather(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids,
-                             const u32* stile_prefix, u32 n_spages, u32 n_stiles, const ChunkRec* chunks,
-                             const PageDyn* page_dyn, const Region* regions, u32 n_regions, const RegionTotal* totals,
-                             int* status);
+hipError_t launch_str_check(hipStream_t st, const PageRec* pages, const ChunkRec* chunks, const PageDyn* page_dyn,
+                            const Region* regions, u32 n_regions, const RegionTotal* totals, int* status);
 hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_prefix, const u32* chunk_ids, u32 n_rchunks,
                        u32 n_rtiles, RowTile* tiles, ChunkDyn* chunk_dyn);
 

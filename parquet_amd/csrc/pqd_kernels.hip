@@ -225,7 +225,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
     // memo per start: exit position, elements passed, and (levels) level values passed.  Levels keep
     // {exit, values} in one 8-byte entry so that a lookup is a single LDS read.
     __shared__ u64 m_tv[KIND == KIND_LEVELS ? MEMO : 1];
-    __shared__ u32 m_tgt[KIND == KIND_LEVELS ? 1 : MEMO];
+    __shared__ __attribute__((aligned(16))) u32 m_tgt[KIND == KIND_LEVELS ? 1 : MEMO];
     __shared__ unsigned short m_cnt[MEMO];
     auto memo_get = [&](u32 mi, u32& tgt, u32& val) {
         if (KIND == KIND_LEVELS) { const u64 e = m_tv[mi]; tgt = (u32)e; val = (u32)(e >> 32); }
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
     __syncthreads();
     // ---- every lane replays its sub-tile from its true entry: one record per true element
     u32 q = e_pos[lane];
-    if (q == ERR_POS) return;
+    if (KIND == KIND_LEVELS && q == ERR_POS) return;
     u32 rank = e_cnt[lane];  // index of the element within the region
     // levels: index of the run's first level value, clamped to the page's value count (32-bit from here on)
     const u32 n_out = (u32)R.n_out;
@@ -412,6 +412,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
         offs = (int32_t*)R.out + pd.val_off;
         cbase = (u32)pd.char_off;  // offsets are int32: a chunk holds less than 2^31 chars
     }
+    u32 smask = 0, last_q = 0, last_nxt = 0;  // strings: true starts of my sub-tile; the last of them
 #pragma unroll
     for (int k = 0; k < (int)CH_SUB; k++) {
         if (q == sub_lo + k && q < L) {
@@ -429,9 +430,69 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
                 // string `rank` of the page starts at q: its chars begin at q + 4; every earlier string of
                 // the page contributed 4 length bytes.  A page never holds more values than levels.
                 if (rank < n_out) offs[rank] = (int32_t)(cbase + q - 4u * rank);
+                smask |= 1u << k;
+                last_q = q;
+                last_nxt = st_nxt[k];
             }
             rank++;
             q = st_nxt[k];
+        }
+    }
+    if (KIND == KIND_STRINGS) {
+        // ---- chars.  The tile owns the strings that start in it.  Every byte of the tile from the true
+        // entry on is either one of their 4 length bytes or one of their chars, and the chars are dense in
+        // the output: char byte number i of the tile goes to chars[g0 + i].  They are compacted through
+        // LDS (the memo table is dead by now) and leave as aligned 16-byte stores; the part of the last
+        // string that lies beyond the tile is copied by the whole wave afterwards.
+        u32 prev = __shfl_up(smask, 1);  // every lane takes part: a masked-off lane would hand its neighbour 0
+        if (lane == 0) prev = 0;
+        const u32 lenmask = smask | (smask << 1) | (smask << 2) | (smask << 3) | ((prev >> 29) & 1) | (((prev >> 30) & 1) * 3) |
+                            (((prev >> 31) & 1) * 7);
+        const u32 lim = te < L ? te : L;
+        const u32 k_lo = ent.pos <= sub_lo ? 0 : ent.pos >= sub_hi ? 32 : ent.pos - sub_lo;
+        const u32 k_hi = lim >= sub_hi ? 32 : lim <= sub_lo ? 0 : lim - sub_lo;
+        u32 own = k_lo >= 32 ? 0 : 0xFFFFFFFFu << k_lo;
+        if (k_hi < 32) own &= (1u << k_hi) - 1;
+        const u32 charmask = own & ~lenmask;
+        // one scan for both counts: chars in the low half, starts in the high half (each <= 2048)
+        const u32 mine = __popc(charmask) | (__popc(smask) << 16);
+        u32 incl = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(incl, d);
+            if (lane >= (u32)d) incl += t;
+        }
+        const u32 total = __shfl(incl, 63);
+        const u32 n_chars = total & 0xFFFF, n_starts = total >> 16;
+        const u32 pc = (incl - mine) & 0xFFFF;
+        const u32 g0 = cbase + ent.pos - 4u * ent.cnt;  // chars index of the tile's first char
+        u8* const cdst = R.out2 + g0;
+        const u32 pad = (u32)((uintptr_t)cdst & 15);
+        u8* const stg = (u8*)m_tgt;
+#pragma unroll
+        for (int k = 0; k < (int)CH_SUB; k++)
+            if ((charmask >> k) & 1) stg[pad + pc + __popc(charmask & ((1u << k) - 1))] = (u8)(w[k >> 2] >> (8 * (k & 3)));
+        __syncthreads();
+        const u32 n_stg = pad + n_chars;
+        for (u32 c0 = lane * 16; c0 < n_stg; c0 += 64 * 16) {
+            if (c0 >= pad && c0 + 16 <= n_stg) *(u32x4*)(cdst - pad + c0) = *(const u32x4*)(stg + c0);
+            else for (u32 b = c0 < pad ? pad : c0; b < c0 + 16 && b < n_stg; b++) cdst[b - pad] = stg[b];
+        }
+        // the last string of the tile may run past the tile: its remaining chars follow directly
+        const u64 has = __ballot(smask != 0);
+        if (has) {
+            const int hl = 63 - __builtin_clzll(has);
+            const u32 lq = __shfl(last_q, hl), ln = __shfl(last_nxt, hl);
+            if (ln != ERR_POS && ln > lim) {
+                const u32 s_lo = lq + 4 > lim ? lq + 4 : lim;
+                const u8* sp = rsrc + s_lo;
+                u8* dp = cdst + n_chars;  // == chars + cbase + s_lo - 4 * (ent.cnt + n_starts)
+                const u32 n = ln - s_lo;
+                for (u32 c0 = lane * 16; c0 < n; c0 += 64 * 16) {
+                    if (c0 + 16 <= n) *(u32x4_u*)(dp + c0) = *(const u32x4_u*)(sp + c0);
+                    else for (u32 b = c0; b < n; b++) dp[b] = sp[b];
+                }
+                (void)n_starts;
+            }
         }
     }
 }
@@ -1018,55 +1079,6 @@ __global__ __launch_bounds__(256) void k_bools(const u8* __restrict__ src_base, 
     }
 }
 
-// =====================================================================================
-// k_str_gather — copies the characters of PLAIN BYTE_ARRAY values into the dense chars array.
-// One thread produces 16 output bytes: it finds the string holding its first byte in the offsets
-// array, then walks forward.
-// =====================================================================================
-__global__ __launch_bounds__(256) void k_str_gather(const u8* __restrict__ src_base, const PageRec* __restrict__ pages,
-                                                    const u32* __restrict__ page_ids, const u32* __restrict__ stile_prefix,
-                                                    u32 n_spages, const ChunkRec* __restrict__ chunks,
-                                                    const PageDyn* __restrict__ page_dyn) {
-    const u32 st = blockIdx.x;
-    const u32 k = find_owner(stile_prefix, n_spages, st);
-    const u32 pg = page_ids[k];
-    const PageRec P = pages[pg];
-    const ChunkRec C = chunks[P.chunk];
-    const PageDyn D = page_dyn[pg];
-    const u64 nn = C.max_def > 0 ? D.nn : P.num_values;
-    if (4 * nn > P.val_len) return;
-    if (nn == 0) return;
-    const u64 page_chars = P.val_len - 4 * nn;
-    const u64 x_rel = (u64)(st - stile_prefix[k]) * ST + threadIdx.x * 16;
-    if (x_rel >= page_chars) return;
-    const int32_t* offs = (const int32_t*)C.offsets;
-    const u64 x0 = D.char_off + x_rel;  // chunk-level char index
-    // last string s in [val_off, val_off + nn) with offs[s] <= x0
-    u64 a = D.val_off, b = D.val_off + nn;
-    while (b - a > 1) { const u64 mid = (a + b) >> 1; if ((u64)offs[mid] <= x0) a = mid; else b = mid; }
-    u64 s = a;
-    const u64 s_end = D.val_off + nn;
-    u64 next_off = s + 1 < s_end ? (u64)offs[s + 1] : D.char_off + page_chars;
-    const u8* src = src_base + P.val_src_off;
-    const u32 n = page_chars - x_rel < 16 ? (u32)(page_chars - x_rel) : 16;
-    u64 lo = 0, hi = 0;
-    for (u32 q = 0; q < n; q++) {
-        const u64 x = x0 + q;
-        while (next_off <= x && s + 1 < s_end) { s++; next_off = s + 1 < s_end ? (u64)offs[s + 1] : D.char_off + page_chars; }
-        // char index x of the chunk is byte (x - char_off) + 4*(strings started so far in the page)
-        const u64 v = src[(x - D.char_off) + 4 * (s - D.val_off + 1)];
-        if (q < 8) lo |= v << (8 * q); else hi |= v << (8 * (q - 8));
-    }
-    u8* dst = C.chars + x0;
-    if (n == 16) {
-        u32x4 v;
-        v.x = (u32)lo; v.y = (u32)(lo >> 32); v.z = (u32)hi; v.w = (u32)(hi >> 32);
-        *(u32x4_u*)dst = v;
-    } else {
-        for (u32 q = 0; q < n; q++) dst[q] = (u8)(q < 8 ? lo >> (8 * q) : hi >> (8 * (q - 8)));
-    }
-}
-
 // Checks after the string chain: every page must hold exactly as many values as its levels say and
 // end on its last byte.
 __global__ void k_str_check(const Region* __restrict__ regions, u32 n_regions, const RegionTotal* __restrict__ totals,
@@ -1149,17 +1161,27 @@ __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunk
         if (threadIdx.x == 0) { tiles[rt].rows = tot_r; tiles[rt].vals = tot_v; }
         return;
     }
-    u64 row = tiles[rt].row_base + br + sr - r;
-    u64 val = tiles[rt].val_base + bv + sv - v;
-    u64* rl = (u64*)C.row_level_off;
-    u64* rv = (u64*)C.row_value_off;
+    // rows of this tile, staged in LDS (tile-relative, 12 bits each) so that the 8-byte stores below are
+    // coalesced: a thread's own row starts are strided in the output
+    __shared__ unsigned short s_rl[WRITE ? RT : 1], s_rv[WRITE ? RT : 1];
+    u32 lrow = br + sr - r;
+    const u32 lval = bv + sv - v;
     u32 m = starts;
     while (m) {
         const u32 b = __ffs(m) - 1;
         m &= m - 1;
-        rl[row] = i0 + b;
-        rv[row] = val + __popc(valid & ((1u << b) - 1));
-        row++;
+        s_rl[lrow] = (unsigned short)(threadIdx.x * 16 + b);
+        s_rv[lrow] = (unsigned short)(lval + __popc(valid & ((1u << b) - 1)));
+        lrow++;
+    }
+    __syncthreads();
+    const RowTile T = tiles[rt];
+    const u64 lvl0 = (u64)(rt - rtile_prefix[k]) * RT;
+    u64* rl = (u64*)C.row_level_off + T.row_base;
+    u64* rv = (u64*)C.row_value_off + T.row_base;
+    for (u32 j = threadIdx.x; j < tot_r; j += 256) {
+        rl[j] = lvl0 + s_rl[j];
+        rv[j] = T.val_base + s_rv[j];
     }
 }
 
@@ -1287,18 +1309,11 @@ hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, con
     return hipSuccess;
 }
 
-hipError_t launch_str_gather(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids,
-                             const u32* stile_prefix, u32 n_spages, u32 n_stiles, const ChunkRec* chunks,
-                             const PageDyn* page_dyn, const Region* regions, u32 n_regions, const RegionTotal* totals,
-                             int* status) {
-    if (n_regions) {
-        hipLaunchKernelGGL(k_str_check, dim3((n_regions + 255) / 256), dim3(256), 0, st, regions, n_regions, totals, pages,
-                           chunks, page_dyn, status);
-        LAUNCH_CHECK();
-    }
-    if (n_stiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_str_gather, dim3(n_stiles), dim3(256), 0, st, src, pages, page_ids, stile_prefix, n_spages, chunks,
-                       page_dyn);
+hipError_t launch_str_check(hipStream_t st, const PageRec* pages, const ChunkRec* chunks, const PageDyn* page_dyn,
+                            const Region* regions, u32 n_regions, const RegionTotal* totals, int* status) {
+    if (n_regions == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_str_check, dim3((n_regions + 255) / 256), dim3(256), 0, st, regions, n_regions, totals, pages, chunks,
+                       page_dyn, status);
     LAUNCH_CHECK();
     return hipSuccess;
 }
