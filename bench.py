@@ -32,8 +32,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pages", type=int, default=None, help="pages per column chunk (default 32 for flat, 8 otherwise)")
-    ap.add_argument("--row-groups", type=int, default=2)
+    ap.add_argument("--pages", type=int, default=None, help="pages per column chunk (default 64 for flat, 8 otherwise)")
+    ap.add_argument("--row-groups", type=int, default=None, help="row groups per GPU (default 4 for flat, 2 otherwise)")
     ap.add_argument("--rows-per-page", type=int, default=1_000_000)
     ap.add_argument("--workload", default="flat", choices=["flat", "optional", "optint", "optstr", "nested"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -197,7 +197,9 @@ def main():
     builders = {"flat": build_flat_file, "optional": build_optional_file, "nested": build_nested_file,
                 "optint": lambda *a: build_optional_file(*a, which="int"),
                 "optstr": lambda *a: build_optional_file(*a, which="str")}
-    pages = args.pages or (32 if args.workload == "flat" else 8)
+    pages = args.pages or (64 if args.workload == "flat" else 8)
+    if args.row_groups is None:
+        args.row_groups = 4 if args.workload == "flat" else 2
     t_build = time.perf_counter()
     # The job's file has world * row_groups row groups (weak scaling); whole row groups go to ranks in
     # contiguous ranges balanced by payload bytes, and each rank materialises only its own shard.

@@ -293,8 +293,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
                     // RLE run of a narrow level: the record carries the value itself (width 0: value 0)
                     const u32 vp = info >> 1, d = vp - p;
                     u32 val = 0;
+                    // the value byte sits 1..8 bytes after p: still inside the lane's 40-byte window
+                    const u32 b8 = (w[(k + 8) >> 2] >> (8 * ((k + 8) & 3))) & 0xFF;
                     if (R.width > 0 && nxt != ERR_POS)
-                        val = d < 4 ? (xlo >> (8 * d)) & 0xFF : d < 8 ? (xhi >> (8 * (d - 4))) & 0xFF : (u32)rsrc[vp];
+                        val = d < 4 ? (xlo >> (8 * d)) & 0xFF : d < 8 ? (xhi >> (8 * (d - 4))) & 0xFF : b8;
                     info = val << 1;
                 }
                 if ((info & 1) && R.width == 0) info = 0;  // width 0 bit-packed groups are runs of zeros

@@ -96,7 +96,12 @@ class ParquetWriter:
         assert N.synth.pqw_finish(self._w) == 0
         n = C.c_int64()
         p = N.synth.pqw_data(self._w, C.byref(n))
-        return C.string_at(p, n.value)
+        if n.value < (1 << 31):
+            return C.string_at(p, n.value)
+        # ctypes.string_at takes a C int: copy larger files into a bytearray
+        out = bytearray(n.value)
+        C.memmove((C.c_char * n.value).from_buffer(out), p, n.value)
+        return out
 
     def finish_into(self, alloc):
         """Like finish(), but copies the file into a buffer obtained from alloc(nbytes) → address."""

@@ -258,6 +258,26 @@ def test_strings_edge_cases(ctx):
         H.check_file(buf, ctx)
 
 
+def test_strings_fixed_strides_and_giants(ctx):
+    """Fixed lengths walk the 4 length bytes over every offset of the 2 KiB chain tiles and 32-byte
+    sub-tiles; the giant strings cover tiles that no string starts in."""
+    rng = np.random.default_rng(16)
+    cols = [Column("s", N.BYTE_ARRAY, [0])]
+    for ln in (1, 13, 27, 28, 29, 61, 2044, 2045):
+        buf = H.build_file(cols, 3000, 3000, 1500, rng, str_len=(ln, ln))
+        H.check_file(buf, ctx)
+    w = ParquetWriter(cols, stats=False)
+    w.begin_row_group()
+    parts = [b"ab", bytes(rng.integers(0, 256, 100001, dtype=np.uint8)), b"", b"xyz",
+             bytes(rng.integers(0, 256, 4096, dtype=np.uint8)), b"q" * 2047, b"tail"]
+    payload = b"".join(len(x).to_bytes(4, "little") + x for x in parts)
+    w.write_raw_page(0, payload, len(parts))
+    w.end_row_group(len(parts))
+    buf = w.finish()
+    o, g = H.check_file(buf, ctx)
+    assert bytes(g[(0, "s")]["chars"]) == b"".join(parts)
+
+
 def test_tiny_and_empty_pages(ctx):
     rng = np.random.default_rng(8)
     cols = [Column("a", N.INT32, [1]), Column("s", N.BYTE_ARRAY, [1]), Column("b", N.BOOLEAN, [1]),
