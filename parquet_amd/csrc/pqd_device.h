@@ -40,6 +40,7 @@ constexpr u32 CH_E_LEVELS = 256;  // tabulated entry positions per tile: covers 
                                   // run (1 + 63 groups x 4 bytes); longer jumps take the serial hop
 constexpr u32 CH_E_STRINGS = 64;  // covers values up to 60 bytes; longer ones take the serial hop
 
+constexpr u32 CH_SERIAL = 64;     // level tiles with at most this many runs are marked by a serial walk
 constexpr u32 CH_G_LEVELS = 8;    // tiles per hop group (level blocks are ~60 tiles per 1M-value page)
 constexpr u32 CH_G_STRINGS = 64;  // tiles per hop group (string pages are thousands of tiles)
 
@@ -65,7 +66,7 @@ struct Region {
 };
 
 struct ExitRec { u32 tgt; u32 cnt; u64 vals; };
-struct TileEntry { u32 pos; u32 cnt; u64 vals; };
+struct TileEntry { u32 pos; u32 cnt; u64 vals; u32 n; u32 pad; };  // n: elements that start in the tile (tile entries only)
 struct RegionTotal { u32 cnt; u32 err; u64 vals; };
 struct RunRec { u32 out_off; u32 info; };
 

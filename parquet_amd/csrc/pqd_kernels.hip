@@ -276,6 +276,55 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
         }
     }
 
+    if (MARK && KIND == KIND_LEVELS && ent.n <= CH_SERIAL) {
+        // ---- few runs start in this tile (long bit-packed or RLE runs, the common case): one lane walks
+        // the true chain through an LDS copy of the tile, then one lane per run emits its record.
+        __shared__ u32 r_out[CH_SERIAL + 1], r_info[CH_SERIAL], r_n;
+        u32* const tb32 = (u32*)m_tv;  // the memo table is not used on this path
+#pragma unroll
+        for (int d = 0; d < 8; d++) tb32[lane * 8 + d] = w[d];
+        if (lane == 63) { tb32[512] = w[8]; tb32[513] = w[9]; tb32[514] = 0; tb32[515] = 0; }
+        __syncthreads();
+        const u32 n_out = (u32)R.n_out;
+        if (lane == 0) {
+            u32 q = ent.pos, i = 0;
+            u32 o = ent.vals < n_out ? (u32)ent.vals : n_out;
+            while (i < ent.n && q < te && q < L) {
+                const u32 rel = q - tb, di = rel >> 2, sh = (rel & 3) * 8;
+                const u32 a = tb32[di], b = tb32[di + 1], c = tb32[di + 2], d3 = tb32[di + 3];
+                const u32 xlo = __builtin_amdgcn_alignbit(b, a, sh), xhi = __builtin_amdgcn_alignbit(c, b, sh);
+                const u32 b8 = __builtin_amdgcn_alignbit(d3, c, sh) & 0xFF;
+                u32 nxt, vals, info;
+                rle_step_w32(xlo, xhi, q, L, R.width, nxt, vals, info);
+                if (!(info & 1) && R.width <= 8) {
+                    const u32 d = (info >> 1) - q;  // the value byte sits 1..8 bytes after q
+                    u32 val = 0;
+                    if (R.width > 0 && nxt != ERR_POS)
+                        val = d < 4 ? (xlo >> (8 * d)) & 0xFF : d < 8 ? (xhi >> (8 * (d - 4))) & 0xFF : b8;
+                    info = val << 1;
+                }
+                if ((info & 1) && R.width == 0) info = 0;  // width 0 bit-packed groups are runs of zeros
+                r_out[i] = o;
+                r_info[i] = info;
+                o = vals < n_out - o ? o + vals : n_out;
+                i++;
+                q = nxt;
+            }
+            r_out[i] = o;
+            r_n = i;
+        }
+        __syncthreads();
+        if (lane < r_n) {
+            const u32 rank = ent.cnt + lane, o = r_out[lane], oe = r_out[lane + 1];
+            RunRec rr;
+            rr.out_off = o;
+            rr.info = r_info[lane];
+            run_tbl[R.run_base + rank] = rr;
+            for (u32 t = (o + OT - 1) / OT; t * OT < oe; t++) otile_first_run[R.otile_base + t] = rank;  // tiles that start inside this run
+        }
+        return;
+    }
+
     // ---- sweep 1: every start of my sub-tile learns where its chain leaves the sub-tile.  The marking
     // pass keeps each start's own step (next start, values, record) in registers for the replay below.
     u32 st_nxt[MARK ? CH_SUB : 1], st_val[MARK && KIND == KIND_LEVELS ? CH_SUB : 1], st_info[MARK && KIND == KIND_LEVELS ? CH_SUB : 1];
@@ -617,9 +666,11 @@ __global__ void k_chain_tiles(const u8* __restrict__ src_base, const Region* __r
     u64 vals = ge.vals;
     while (p < g_hi) {
         TileEntry te;
-        te.pos = p; te.cnt = cnt; te.vals = vals;
-        tile_entry[R.tile_base + p / CH_T] = te;
+        te.pos = p; te.cnt = cnt; te.vals = vals; te.pad = 0;
+        const u32 idx = R.tile_base + p / CH_T;
         p = hop_tile<KIND>(R, B, exit_tbl, p, cnt, vals);
+        te.n = cnt - te.cnt;
+        tile_entry[idx] = te;
     }
 }
 
