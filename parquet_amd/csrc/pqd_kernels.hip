@@ -1190,6 +1190,7 @@ __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunk
         const u32 in_range = n - i0 >= 16 ? 0xFFFFu : (1u << (n - i0)) - 1;
         valid = eq_mask16(load16_guarded(C.defs, i0, n), (u32)C.max_def) & in_range;
         starts = C.max_rep > 0 ? eq_mask16(load16_guarded(C.reps, i0, n), 0) & in_range : in_range;
+        if (i0 == 0) starts |= 1;  // the first level opens a row whatever its rep level (write_repeated.go:62-80)
     }
     if (!WRITE) {
         // validity bitmap: 16 bits per thread

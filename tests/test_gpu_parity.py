@@ -278,6 +278,16 @@ def test_strings_fixed_strides_and_giants(ctx):
     assert bytes(g[(0, "s")]["chars"]) == b"".join(parts)
 
 
+def test_strings_that_look_like_length_prefixes(ctx):
+    """Chars drawn from {0, 1, 2}: almost every byte of the page is a plausible length prefix, so the false
+    candidate chains of the chain kernels are as long as they can get."""
+    rng = np.random.default_rng(17)
+    cols = [Column("s", N.BYTE_ARRAY, [0]), Column("o", N.BYTE_ARRAY, [1])]
+    for lo, hi in ((0, 40), (0, 5), (30, 300)):
+        buf = H.build_file(cols, 20000, 20000, 6000, rng, p_null=0.3, str_len=(lo, hi), alphabet=(0, 3))
+        H.check_file(buf, ctx)
+
+
 def test_tiny_and_empty_pages(ctx):
     rng = np.random.default_rng(8)
     cols = [Column("a", N.INT32, [1]), Column("s", N.BYTE_ARRAY, [1]), Column("b", N.BOOLEAN, [1]),
@@ -481,3 +491,75 @@ def test_performance_message_schema(ctx):
     assert pf.num_columns == 40 and pf.num_row_groups == n_groups and pf.row_group_rows(0) == 1
     H.check_file(buf, ctx)            # all row groups in one batch
     H.check_file(buf, ctx, rg_batch=1)  # one readRowGroup per call, as the reference reader does
+
+
+# ---------------------------------------------------------------- fuzz: hand-built level blocks through the page path
+def _leb(h, rng, pad_ok=True):
+    out = []
+    while True:
+        b = h & 0x7F
+        h >>= 7
+        if h:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            break
+    if pad_ok and rng.random() < 0.1:  # non-canonical: continuation bytes that add nothing (readLEB128 accepts them)
+        extra = int(rng.integers(1, 9 - len(out))) if len(out) < 8 else 0
+        if extra:
+            out[-1] |= 0x80
+            out += [0x80] * (extra - 1) + [0x00]
+    return bytes(out)
+
+
+def _random_level_block(rng, width, min_values):
+    """A hybrid RLE/bit-packed block no encoder would write: empty runs, runs of 1, long runs, zero-group
+    bit-packed headers, random packed bytes, padded headers."""
+    body = bytearray()
+    total = 0
+    while total < min_values:
+        if rng.random() < 0.5:
+            count = int(rng.choice([0, 1, 2, 7, 8, 9, 100, int(rng.integers(0, 6000))]))
+            body += _leb(count << 1, rng) + bytes([int(rng.integers(0, 1 << width))])
+            total += count
+        else:
+            groups = int(rng.choice([0, 1, 2, 3, 63, 64, int(rng.integers(0, 300))]))
+            body += _leb((groups << 1) | 1, rng) + bytes(rng.integers(0, 256, groups * width, dtype=np.uint8))
+            total += 8 * groups
+    return len(body).to_bytes(4, "little") + bytes(body), total
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_fuzz_level_blocks_through_pages(ctx, seed):
+    rng = np.random.default_rng(100 + seed)
+    shapes = [[1], [1, 1, 1], [1] * 7, [1] * 15, [2], [2, 1, 2], [1, 2, 1, 2, 1]]
+    cols = [Column(".".join("c%dn%d" % (ci, i) for i in range(len(t))), N.INT32, t) for ci, t in enumerate(shapes)]
+    w = ParquetWriter(cols, stats=False)
+    w.begin_row_group()
+    for ci, t in enumerate(shapes):
+        max_def = sum(1 for x in t if x in (OPTIONAL, REPEATED))
+        max_rep = sum(1 for x in t if x == REPEATED)
+        n_total = 0
+        for _ in range(int(rng.integers(1, 5))):
+            want = int(rng.choice([1, 5, 4095, 4096, 4097, 20000, int(rng.integers(1, 60000))]))
+            # def block: random runs, then a run of 8 zeros that DataPageHeader.num_values may cut anywhere
+            # (cut-off levels equal to max_def would make the reference read more values than the page has)
+            dwidth = int(max_def).bit_length()
+            dblock, dtotal = _random_level_block(rng, dwidth, want)
+            dblock = (len(dblock) - 4 + 2).to_bytes(4, "little") + dblock[4:] + bytes([8 << 1, 0])
+            n = dtotal + int(rng.integers(0, 9))
+            payload = b""
+            if max_rep:
+                rblock, _ = _random_level_block(rng, int(max_rep).bit_length(), dtotal + 8)
+                payload += rblock
+            payload += dblock
+            levels, _ = O.rle_read(dwidth, dblock)
+            n = max(n, 1)
+            nn = int(np.count_nonzero(np.asarray(levels[:n]) == max_def))
+            payload += rng.integers(-2**31, 2**31 - 1, nn, dtype=np.int64).astype(np.int32).tobytes()
+            w.write_raw_page(ci, payload, n)
+            n_total += n
+    w.end_row_group(1)
+    buf = w.finish()
+    w.close()
+    H.check_file(buf, ctx)
