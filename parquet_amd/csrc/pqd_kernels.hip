@@ -548,6 +548,182 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
     }
 }
 
+// =====================================================================================
+// PLAIN BYTE_ARRAY chains.  A length prefix is cheap to parse and a wrong start dies fast (a random
+// length overshoots the page), so strings do not need the every-byte sweep of k_chain:
+//   k_str_exits   pass 1: lane i follows the chain that starts at byte i of the tile (i < E = 64)
+//                 through an LDS copy of the tile until it leaves the tile; the exit table gets where it
+//                 left and how many strings it passed.  Same table, same hop kernels as the level chains.
+//   k_str_mark    pass 2: lane 0 walks the true chain from the tile's true entry and sets one bit per
+//                 string start; the wave then writes offsets[] (rank = prefix popcount) and the chars:
+//                 every byte of the tile from the true entry on is a length byte or a char, chars are
+//                 dense in the output, so they are compacted through LDS and leave as aligned 16-byte
+//                 stores; the part of the tile's last string beyond the tile is copied by the whole wave.
+// =====================================================================================
+constexpr u32 STR_LDS_WORDS = CH_T / 4 + 4;
+
+// loads the lane's 32 bytes of the tile (zero past L) into w[0..7] and into the LDS image
+static __device__ __forceinline__ void str_stage_tile(const u8* rsrc, u32 L, u32 tb, u32 lane, u32 (&w)[8], u32* s_tile) {
+    const u32 sub_lo = tb + lane * CH_SUB;
+    if (sub_lo + CH_SUB <= L) {
+        const u32x4 a = *(const u32x4_u*)(rsrc + sub_lo), b = *(const u32x4_u*)(rsrc + sub_lo + 16);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const u32 p = sub_lo + 4 * d;
+            u32 v = 0;
+            if (p < L) {
+                if (L - p >= 4) v = *(const u32_u*)(rsrc + p);
+                else for (u32 k = 0; k < L - p; k++) v |= (u32)rsrc[p + k] << (8 * k);
+            }
+            w[d] = v;
+        }
+    }
+    *(u32x4*)(s_tile + lane * 8) = u32x4{w[0], w[1], w[2], w[3]};
+    *(u32x4*)(s_tile + lane * 8 + 4) = u32x4{w[4], w[5], w[6], w[7]};
+    if (lane == 0) {
+        // 4 bytes of lookahead: a length prefix may start in the last 3 bytes of the tile
+        const u32 p = tb + CH_T;
+        u32 v = 0;
+        if (p < L) {
+            if (L - p >= 4) v = *(const u32_u*)(rsrc + p);
+            else for (u32 k = 0; k < L - p; k++) v |= (u32)rsrc[p + k] << (8 * k);
+        }
+        s_tile[CH_T / 4] = v;
+        s_tile[CH_T / 4 + 1] = 0;
+    }
+}
+// the 4 bytes at tile offset rel (rel < CH_T) of the LDS image
+static __device__ __forceinline__ u32 str_len_at(const u32* s_tile, u32 rel) {
+    const u32 d = rel >> 2;
+    return __builtin_amdgcn_alignbit(s_tile[d + 1], s_tile[d], (rel & 3) * 8);
+}
+
+__global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                                                          const u32* __restrict__ tile_prefix, u32 n_regions,
+                                                          ExitRec* __restrict__ exit_tbl) {
+    static_assert(CH_E_STRINGS == CH_THREADS, "one lane per tabulated entry");
+    __shared__ __attribute__((aligned(16))) u32 s_tile[STR_LDS_WORDS];
+    const u32 lane = threadIdx.x, tile = blockIdx.x;
+    const u32 ri = find_owner(tile_prefix, n_regions, tile);
+    const Region R = regions[ri];
+    const u32 L = R.len;
+    const u32 tb = (tile - tile_prefix[ri]) * CH_T;
+    const u32 lim = tb + CH_T < L ? tb + CH_T : L;
+    u32 w[8];
+    str_stage_tile(src_base + R.src_off, L, tb, lane, w, s_tile);
+    __syncthreads();
+    u32 q = tb + lane, cnt = 0;
+    while (q < lim) {  // ERR_POS ends the loop too
+        u32 nxt;
+        str_step_win(str_len_at(s_tile, q - tb), q, L, nxt);
+        cnt++;
+        q = nxt;
+    }
+    ExitRec x;
+    x.tgt = q; x.cnt = cnt; x.vals = 0;
+    exit_tbl[(u64)tile * CH_E_STRINGS + lane] = x;
+}
+
+__global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                                                         const u32* __restrict__ tile_prefix, u32 n_regions,
+                                                         const TileEntry* __restrict__ tile_entry,
+                                                         const PageDyn* __restrict__ page_dyn) {
+    __shared__ __attribute__((aligned(16))) u32 s_tile[STR_LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) u8 s_stage[CH_T + 16];
+    __shared__ u32 s_bits[64], s_last[2];
+    const u32 lane = threadIdx.x, tile = blockIdx.x;
+    const TileEntry ent = tile_entry[tile];
+    if (ent.pos == ERR_POS) return;  // no string starts in this tile
+    const u32 ri = find_owner(tile_prefix, n_regions, tile);
+    const Region R = regions[ri];
+    const u32 L = R.len;
+    const u32 tb = (tile - tile_prefix[ri]) * CH_T, te = tb + CH_T;
+    const u32 lim = te < L ? te : L;
+    const u8* rsrc = src_base + R.src_off;
+    const u32 sub_lo = tb + lane * CH_SUB, sub_hi = sub_lo + CH_SUB;
+    u32 w[8];
+    str_stage_tile(rsrc, L, tb, lane, w, s_tile);
+    s_bits[lane] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        u32 q = ent.pos, last_q = ent.pos, last_nxt = ERR_POS;
+        while (q < lim) {
+            const u32 rel = q - tb;
+            s_bits[rel >> 5] |= 1u << (rel & 31);
+            u32 nxt;
+            str_step_win(str_len_at(s_tile, rel), q, L, nxt);
+            last_q = q;
+            last_nxt = nxt;
+            q = nxt;
+        }
+        s_last[0] = last_q;
+        s_last[1] = last_nxt;
+    }
+    __syncthreads();
+    const u32 smask = s_bits[lane];  // true string starts of my sub-tile
+    u32 prev = __shfl_up(smask, 1);  // every lane takes part: a masked-off lane would hand its neighbour 0
+    if (lane == 0) prev = 0;
+    const u32 lenmask = smask | (smask << 1) | (smask << 2) | (smask << 3) | ((prev >> 29) & 1) | (((prev >> 30) & 1) * 3) |
+                        (((prev >> 31) & 1) * 7);
+    const u32 k_lo = ent.pos <= sub_lo ? 0 : ent.pos >= sub_hi ? 32 : ent.pos - sub_lo;
+    const u32 k_hi = lim >= sub_hi ? 32 : lim <= sub_lo ? 0 : lim - sub_lo;
+    u32 own = k_lo >= 32 ? 0 : 0xFFFFFFFFu << k_lo;
+    if (k_hi < 32) own &= (1u << k_hi) - 1;
+    const u32 charmask = own & ~lenmask;
+    // one scan for both counts: chars in the low half, starts in the high half (each <= 2048)
+    const u32 mine = __popc(charmask) | (__popc(smask) << 16);
+    u32 incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(incl, d);
+        if (lane >= (u32)d) incl += t;
+    }
+    const u32 total = __shfl(incl, 63);
+    const u32 n_chars = total & 0xFFFF;
+    const u32 pc = (incl - mine) & 0xFFFF, ps = (incl - mine) >> 16;
+    const PageDyn pd = page_dyn[R.page];
+    const u32 cbase = (u32)pd.char_off;  // offsets are int32: a chunk holds less than 2^31 chars
+    // offsets: string `rank` of the page starts at q, its chars at q + 4; every earlier string of the page
+    // contributed 4 length bytes.  A page never holds more values than levels.
+    {
+        int32_t* const offs = (int32_t*)R.out + pd.val_off;
+        const u32 n_out = (u32)R.n_out;
+        u32 m = smask, rank = ent.cnt + ps;
+        while (m) {
+            const u32 k = __ffs(m) - 1;
+            m &= m - 1;
+            if (rank < n_out) offs[rank] = (int32_t)(cbase + (sub_lo + k) - 4u * rank);
+            rank++;
+        }
+    }
+    // chars: char byte number i of the tile goes to chars[g0 + i]
+    const u32 g0 = cbase + ent.pos - 4u * ent.cnt;
+    u8* const cdst = R.out2 + g0;
+    const u32 pad = (u32)((uintptr_t)cdst & 15);
+#pragma unroll
+    for (int k = 0; k < (int)CH_SUB; k++)
+        if ((charmask >> k) & 1) s_stage[pad + pc + __popc(charmask & ((1u << k) - 1))] = (u8)(w[k >> 2] >> (8 * (k & 3)));
+    __syncthreads();
+    const u32 n_stg = pad + n_chars;
+    for (u32 c0 = lane * 16; c0 < n_stg; c0 += 64 * 16) {
+        if (c0 >= pad && c0 + 16 <= n_stg) *(u32x4*)(cdst - pad + c0) = *(const u32x4*)(s_stage + c0);
+        else for (u32 b = c0 < pad ? pad : c0; b < c0 + 16 && b < n_stg; b++) cdst[b - pad] = s_stage[b];
+    }
+    // the last string of the tile may run past the tile: its remaining chars follow directly
+    const u32 lq = s_last[0], ln = s_last[1];
+    if (ln != ERR_POS && ln > lim) {
+        const u32 s_lo = lq + 4 > lim ? lq + 4 : lim;
+        const u8* sp = rsrc + s_lo;
+        u8* dp = cdst + n_chars;
+        const u32 n = ln - s_lo;
+        for (u32 c0 = lane * 16; c0 < n; c0 += 64 * 16) {
+            if (c0 + 16 <= n) *(u32x4_u*)(dp + c0) = *(const u32x4_u*)(sp + c0);
+            else for (u32 b = c0; b < n; b++) dp[b] = sp[b];
+        }
+    }
+}
+
 // ---- hopping from tile to tile along the true chain, in three levels so that no thread makes more
 // than a few dozen dependent loads:
 //   k_chain_groups    per group of G tiles and per tabulated entry of its first tile: where the chain
@@ -1296,8 +1472,12 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
     if (a.n_regions == 0) return hipSuccess;
     if (phase == 0) {
         if (a.n_tiles) {
-            hipLaunchKernelGGL((k_chain<KIND, false>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix,
-                               a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn);
+            if (KIND == KIND_STRINGS)
+                hipLaunchKernelGGL(k_str_exits, dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix,
+                                   a.n_regions, a.exit_tbl);
+            else
+                hipLaunchKernelGGL((k_chain<KIND, false>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions,
+                                   a.tile_prefix, a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn);
             LAUNCH_CHECK();
             hipLaunchKernelGGL((k_chain_groups<KIND>), dim3(a.n_groups * (E / 64)), dim3(64), 0, st, src, a.regions,
                                a.group_prefix, a.n_regions, a.exit_tbl, a.gexit);
@@ -1313,8 +1493,12 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
             LAUNCH_CHECK();
         }
     } else if (a.n_tiles) {
-        hipLaunchKernelGGL((k_chain<KIND, true>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix,
-                           a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn);
+        if (KIND == KIND_STRINGS)
+            hipLaunchKernelGGL(k_str_mark, dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix, a.n_regions,
+                               a.tile_entry, page_dyn);
+        else
+            hipLaunchKernelGGL((k_chain<KIND, true>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix,
+                               a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn);
         LAUNCH_CHECK();
     }
     return hipSuccess;
