@@ -411,6 +411,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     // scratch
     const size_t o_lexit = ap.take((size_t)pl->n_ltiles * CH_E_LEVELS * sizeof(ExitRec));
     const size_t o_sexit = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * sizeof(ExitRec));
+    const size_t o_scp = ap.take((size_t)pl->n_stiles_chain * CH_THREADS * 16);
     const u32 n_lgroups = pl->lgroup_prefix.back(), n_sgroups = pl->sgroup_prefix.back();
     const size_t o_lgexit = ap.take((size_t)n_lgroups * CH_E_LEVELS * sizeof(ExitRec));
     const size_t o_sgexit = ap.take((size_t)n_sgroups * CH_E_STRINGS * sizeof(ExitRec));
@@ -514,7 +515,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->lchain = ChainArgs{pl->d_lregions, pl->d_ltile_prefix, pl->d_lgroup_prefix, (u32)pl->lregions.size(), pl->n_ltiles, n_lgroups,
                            pl->d_lexit, pl->d_lgexit, pl->d_ltile_entry, pl->d_lgroup_entry, pl->d_ltotals};
     pl->schain = ChainArgs{pl->d_sregions, pl->d_stile_chain_prefix, pl->d_sgroup_prefix, (u32)pl->sregions.size(), pl->n_stiles_chain,
-                           n_sgroups, pl->d_sexit, pl->d_sgexit, pl->d_stile_entry, pl->d_sgroup_entry, pl->d_stotals};
+                           n_sgroups, pl->d_sexit, pl->d_sgexit, pl->d_stile_entry, pl->d_sgroup_entry, pl->d_stotals, A + o_scp};
 
     int rc;
     if ((rc = upload(ctx, pl->d_chunks, pl->chunks))) return rc;

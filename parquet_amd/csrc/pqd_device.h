@@ -111,6 +111,7 @@ struct ChainArgs {
     TileEntry* tile_entry;    // n_tiles   (reset to 0xFF before every run)
     TileEntry* group_entry;   // n_groups  (reset to 0xFF before every run)
     RegionTotal* totals;      // n_regions
+    void* str_cp;             // strings: n_tiles * 64 rows of 8 u16 walk checkpoints (1 KiB per tile)
 };
 hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs& a, RunRec* run_tbl, u32* otile_first_run,
                         const PageDyn* page_dyn, int* status, int phase);

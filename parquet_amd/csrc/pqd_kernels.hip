@@ -561,6 +561,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
 //                 stores; the part of the tile's last string beyond the tile is copied by the whole wave.
 // =====================================================================================
 constexpr u32 STR_LDS_WORDS = CH_T / 4 + 4;
+constexpr u32 STR_CP = 8;                       // checkpoints per chain (slot 0 unused)
+constexpr u32 STR_CP_BYTES = CH_T / STR_CP;     // one every 256 bytes
+static_assert(STR_CP * 2 == 16, "a checkpoint row is one 16-byte store");
 
 // loads the lane's 32 bytes of the tile (zero past L) into w[0..7] and into the LDS image
 static __device__ __forceinline__ void str_stage_tile(const u8* rsrc, u32 L, u32 tb, u32 lane, u32 (&w)[8], u32* s_tile) {
@@ -602,9 +605,12 @@ static __device__ __forceinline__ u32 str_len_at(const u32* s_tile, u32 rel) {
 
 __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                           const u32* __restrict__ tile_prefix, u32 n_regions,
-                                                          ExitRec* __restrict__ exit_tbl) {
+                                                          ExitRec* __restrict__ exit_tbl, u32x4* __restrict__ str_cp) {
     static_assert(CH_E_STRINGS == CH_THREADS, "one lane per tabulated entry");
     __shared__ __attribute__((aligned(16))) u32 s_tile[STR_LDS_WORDS];
+    // checkpoints: the first position of the lane's chain inside each 256-byte block of the tile (tile
+    // offset; 0xFFFF = none).  Pass 2 splits its walk of the true chain at them.
+    __shared__ __attribute__((aligned(16))) unsigned short s_cp[CH_THREADS * STR_CP];
     const u32 lane = threadIdx.x, tile = blockIdx.x;
     const u32 ri = find_owner(tile_prefix, n_regions, tile);
     const Region R = regions[ri];
@@ -614,21 +620,29 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
     u32 w[8];
     str_stage_tile(src_base + R.src_off, L, tb, lane, w, s_tile);
     __syncthreads();
-    u32 q = tb + lane, cnt = 0;
+    *(u32x4*)(s_cp + lane * STR_CP) = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    u32 q = tb + lane, cnt = 0, kprev = 0;
     while (q < lim) {  // ERR_POS ends the loop too
+        const u32 rel = q - tb, k = rel / STR_CP_BYTES;
+        if (k != kprev) {  // first position of the chain inside 256-byte block k
+            s_cp[lane * STR_CP + k] = (unsigned short)rel;
+            kprev = k;
+        }
         u32 nxt;
-        str_step_win(str_len_at(s_tile, q - tb), q, L, nxt);
+        str_step_win(str_len_at(s_tile, rel), q, L, nxt);
         cnt++;
         q = nxt;
     }
     ExitRec x;
     x.tgt = q; x.cnt = cnt; x.vals = 0;
     exit_tbl[(u64)tile * CH_E_STRINGS + lane] = x;
+    str_cp[(u64)tile * CH_THREADS + lane] = *(const u32x4*)(s_cp + lane * STR_CP);  // own row: no barrier needed
 }
 
 __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                          const u32* __restrict__ tile_prefix, u32 n_regions,
                                                          const TileEntry* __restrict__ tile_entry,
+                                                         const u32x4* __restrict__ str_cp,
                                                          const PageDyn* __restrict__ page_dyn) {
     __shared__ __attribute__((aligned(16))) u32 s_tile[STR_LDS_WORDS];
     __shared__ __attribute__((aligned(16))) u8 s_stage[CH_T + 16];
@@ -647,19 +661,34 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
     str_stage_tile(rsrc, L, tb, lane, w, s_tile);
     s_bits[lane] = 0;
     __syncthreads();
-    if (lane == 0) {
-        u32 q = ent.pos, last_q = ent.pos, last_nxt = ERR_POS;
-        while (q < lim) {
+    // The true chain is walked by up to 8 lanes at once: pass 1 left, for the chain of every tabulated entry,
+    // its first position inside each 256-byte block of the tile; lane j walks block j.
+    // An entry beyond the tabulated window (a long string ends here) is walked by lane 0 alone.
+    if (lane < STR_CP) {
+        const u32 e = ent.pos - tb;
+        u32 q = ERR_POS, end = lim;
+        if (e >= CH_E_STRINGS) { if (lane == 0) q = ent.pos; }
+        else {
+            const unsigned short cp = ((const unsigned short*)(str_cp + (u64)tile * CH_THREADS + e))[lane];
+            if (lane == 0) q = ent.pos;
+            else if (cp != 0xFFFF) q = tb + cp;
+            const u32 b = tb + (lane + 1) * STR_CP_BYTES;
+            end = b < lim ? b : lim;
+        }
+        u32 last_q = q, last_nxt = ERR_POS;
+        bool walked = false;
+        while (q < end) {
             const u32 rel = q - tb;
-            s_bits[rel >> 5] |= 1u << (rel & 31);
+            atomicOr(&s_bits[rel >> 5], 1u << (rel & 31));
             u32 nxt;
             str_step_win(str_len_at(s_tile, rel), q, L, nxt);
             last_q = q;
             last_nxt = nxt;
             q = nxt;
+            walked = true;
         }
-        s_last[0] = last_q;
-        s_last[1] = last_nxt;
+        // the lane whose walk left the tile (or hit a bad length) holds the tile's last string
+        if (walked && q >= lim) { s_last[0] = last_q; s_last[1] = last_nxt; }
     }
     __syncthreads();
     const u32 smask = s_bits[lane];  // true string starts of my sub-tile
@@ -1474,7 +1503,7 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
         if (a.n_tiles) {
             if (KIND == KIND_STRINGS)
                 hipLaunchKernelGGL(k_str_exits, dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix,
-                                   a.n_regions, a.exit_tbl);
+                                   a.n_regions, a.exit_tbl, (u32x4*)a.str_cp);
             else
                 hipLaunchKernelGGL((k_chain<KIND, false>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions,
                                    a.tile_prefix, a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn);
@@ -1495,7 +1524,7 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
     } else if (a.n_tiles) {
         if (KIND == KIND_STRINGS)
             hipLaunchKernelGGL(k_str_mark, dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix, a.n_regions,
-                               a.tile_entry, page_dyn);
+                               a.tile_entry, (const u32x4*)a.str_cp, page_dyn);
         else
             hipLaunchKernelGGL((k_chain<KIND, true>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix,
                                a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn);
