@@ -122,7 +122,7 @@ def oracle_file(buf, pf=None):
                 break
             name, ci = pf.columns[m["column"]]
             ch = O.read_chunk(buf, m["start_pos"], ci.phys_type, ci.max_def, ci.max_rep, m["num_values"],
-                              m["total_compressed_size"])
+                              m["total_compressed_size"], codec=pf.chunk_codec(rg, c))
             ch.max_def, ch.max_rep, ch.phys_type = ci.max_def, ci.max_rep, ci.phys_type
             out[(rg, name)] = ch
     return out

@@ -35,7 +35,7 @@ class _Chunk(C.Structure):
         ("n_defs", C.c_int64), ("n_reps", C.c_int64),
         ("values", C.POINTER(C.c_uint8)), ("values_len", C.c_int64), ("n_values", C.c_int64),
         ("offsets", C.POINTER(C.c_int32)), ("sizes", C.POINTER(C.c_int64)),
-        ("n_pages", C.c_int64), ("consumed", C.c_int64),
+        ("n_pages", C.c_int64), ("consumed", C.c_int64), ("codec", C.c_int32),
     ]
 
 
@@ -61,6 +61,10 @@ def _load():
     lib.pqo_free.restype = None
     lib.pqo_page_header.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(PageHeader)]
     lib.pqo_read_chunk.argtypes = [C.c_void_p, C.c_size_t, C.c_int64, C.POINTER(_Chunk)]
+    lib.pqo_snappy_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.pqo_snappy_decode.restype = C.c_int64
+    lib.pqo_snappy_decoded_len.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.pqo_snappy_decoded_len.restype = C.c_int64
     lib.pqo_chunk_free.argtypes = [C.POINTER(_Chunk)]
     lib.pqo_chunk_free.restype = None
     lib.pqo_row_offsets.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
@@ -154,11 +158,12 @@ class Chunk:
                  "max_def", "max_rep", "phys_type")
 
 
-def read_chunk(file_bytes, pos, phys_type, max_def, max_rep, pg_n, pg_size):
+def read_chunk(file_bytes, pos, phys_type, max_def, max_rep, pg_n, pg_size, codec=0):
     """Restatement of Field.Read for one column chunk starting at file offset `pos`."""
     buf = np.frombuffer(file_bytes, dtype=np.uint8)
     c = _Chunk()
     c.phys_type, c.max_def, c.max_rep, c.pg_n, c.pg_size = phys_type, max_def, max_rep, pg_n, pg_size
+    c.codec = codec
     rc = lib.pqo_read_chunk(buf.ctypes.data, buf.size, pos, C.byref(c))
     out = Chunk()
     out.error = rc
@@ -178,6 +183,20 @@ def read_chunk(file_bytes, pos, phys_type, max_def, max_rep, pg_n, pg_size):
     finally:
         lib.pqo_chunk_free(C.byref(c))
     return out
+
+
+def snappy_decode(data):
+    """snappy.Decode (golang/snappy v0.0.2) of one raw-format block.  Returns (bytes, 0) or (None, error)."""
+    src = np.frombuffer(bytes(data), np.uint8)
+    hdr = C.c_size_t()
+    n = lib.pqo_snappy_decoded_len(src.ctypes.data, src.size, C.byref(hdr))
+    if n < 0:
+        return None, int(n)
+    dst = np.zeros(max(n, 1), np.uint8)
+    got = lib.pqo_snappy_decode(src.ctypes.data, src.size, dst.ctypes.data, n)
+    if got < 0:
+        return None, int(got)
+    return dst[:n].tobytes(), 0
 
 
 def row_offsets(defs, reps, max_def, max_rep):
