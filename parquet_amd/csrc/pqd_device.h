@@ -31,7 +31,7 @@ struct Seg {
 };
 
 // ---- chain resolution (run headers, BYTE_ARRAY lengths) ---------------------------------------
-constexpr int KIND_LEVELS = 0, KIND_STRINGS = 1;
+constexpr int KIND_LEVELS = 0, KIND_STRINGS = 1, KIND_SNAPPY = 2;
 constexpr u32 CH_SUB = 32;        // source bytes per lane (sub-tile)
 constexpr u32 CH_THREADS = 64;    // one wavefront per tile
 constexpr u32 CH_T = CH_THREADS * CH_SUB;  // source bytes per tile (2048)
@@ -45,6 +45,7 @@ constexpr u32 CH_G_LEVELS = 8;    // tiles per hop group (level blocks are ~60 t
 constexpr u32 CH_G_STRINGS = 64;  // tiles per hop group (string pages are thousands of tiles)
 
 constexpr u32 OT = 4096;          // level values per expand tile
+constexpr u32 SN_T = 65536;       // snappy: output bytes per decode tile (the block size of the usual encoders)
 constexpr u32 EX_CAP = 1024;      // runs staged in LDS per expand batch
 constexpr u32 BT = 4096;          // bools per tile
 constexpr u32 RT = 4096;          // levels per row-offset tile
@@ -128,5 +129,13 @@ hipError_t launch_str_check(hipStream_t st, const PageRec* pages, const ChunkRec
                             const Region* regions, u32 n_regions, const RegionTotal* totals, int* status);
 hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_prefix, const u32* chunk_ids, u32 n_rchunks,
                        u32 n_rtiles, RowTile* tiles, ChunkDyn* chunk_dyn);
+
+// snappy: decode tiles of SN_T output bytes from the element records (otile_region / otile_first_run have one
+// spare entry each); every Region.out must be 16-byte aligned
+hipError_t launch_snappy_tiles(hipStream_t st, const u8* src, const Region* regions, const u32* otile_region, u32 n_otiles,
+                               const RunRec* run_tbl, const u32* otile_first_run, const RegionTotal* totals, int* status);
+// sizes[2*i], sizes[2*i+1] = rep / def level block bytes of page i (PageRec.val_src_off / val_len = its whole payload)
+hipError_t launch_level_block_sizes(hipStream_t st, const u8* src, const PageRec* pages, const ChunkRec* chunks, u32 n_pages,
+                                    int* sizes);
 
 }  // namespace pqd

@@ -201,6 +201,52 @@ static __device__ __forceinline__ void str_step(const Bytes& B, u32 p, u32 L, u3
     str_step_win(len, p, L, nxt);
 }
 
+// One snappy element at region position p (p < L), given the 8 bytes at p (decode of golang/snappy,
+// called by pageData, fields.go:361-371):
+//   tag & 3 == 0  literal: (tag >> 2) + 1 bytes, or 1..4 extra little-endian length bytes for 60..63
+//   tag & 3 == 1  copy: 4 + ((tag >> 2) & 7) bytes from offset ((tag & 0xE0) << 3) | next byte
+//   tag & 3 == 2/3 copy: 1 + (tag >> 2) bytes from the offset in the next 2 / 4 bytes
+// nxt = position of the next element, vals = bytes it produces,
+// info = (position of the literal bytes) << 1, or (offset << 1) | 1 for a copy.  A cut-off element, a
+// literal running past the block, offset 0 and offsets of 2^31 and more are ERR_POS; whether a copy
+// reaches back before the start of the output is checked where the output position is known.
+static __device__ __forceinline__ void snappy_step_w32(u32 lo, u32 hi, u32 p, u32 L, u32& nxt, u32& vals, u32& info) {
+    const u32 tag = lo & 0xFF, type = tag & 3, x6 = tag >> 2;
+    const u32 rem = L - p;
+    const u32 b1234 = (lo >> 8) | (hi << 24);  // the 4 bytes after the tag
+    // literal
+    const u32 nb = x6 < 60 ? 0 : x6 - 59;
+    const u32 ext = nb == 4 ? b1234 : b1234 & ((1u << (8 * nb)) - 1);
+    const u32 lit_len = (nb ? ext : x6) + 1;  // 0 after overflow: an unsupported literal length
+    // copies
+    const u32 c_len = type == 1 ? 4 + (x6 & 7) : 1 + x6;
+    const u32 c_off = type == 1 ? ((tag & 0xE0) << 3) | (b1234 & 0xFF) : type == 2 ? b1234 & 0xFFFF : b1234;
+    const u32 hdr = type == 0 ? 1 + nb : type == 1 ? 2 : type == 2 ? 3 : 5;
+    const bool lit = type == 0;
+    bool bad = hdr > rem;
+    bad = bad | (lit ? ((lit_len == 0) | (lit_len > rem - hdr)) : ((c_off == 0) | (c_off >= 0x80000000u)));
+    nxt = bad ? ERR_POS : (lit ? p + hdr + lit_len : p + hdr);
+    vals = bad ? 0u : (lit ? lit_len : c_len);
+    info = bad ? 0u : (lit ? (p + hdr) << 1 : (c_off << 1) | 1u);
+}
+
+// the element step of a chain kind
+template <int KIND>
+static __device__ __forceinline__ void elem_step_w32(u32 lo, u32 hi, u32 p, u32 L, u32 w, u32& nxt, u32& vals, u32& info) {
+    if (KIND == KIND_SNAPPY) snappy_step_w32(lo, hi, p, L, nxt, vals, info);
+    else rle_step_w32(lo, hi, p, L, w, nxt, vals, info);
+}
+template <int KIND, class Bytes>
+static __device__ __forceinline__ void elem_step(const Bytes& B, u32 p, u32 L, u32 w, u32& nxt, u64& vals, u32& info) {
+    if (KIND == KIND_SNAPPY) {
+        u32 x[2] = {0, 0};
+        for (u32 k = 0; k < 8 && p + k < L; k++) x[k >> 2] |= B(p + k) << (8 * (k & 3));
+        u32 v;
+        snappy_step_w32(x[0], x[1], p, L, nxt, v, info);
+        vals = v;
+    } else rle_step(B, p, L, w, nxt, vals, info);
+}
+
 // Bytes k..k+7 / k..k+3 of a lane's register image w[] (its sub-tile plus 8 bytes of lookahead); k is a
 // compile-time constant after unrolling, so these are plain register funnel shifts.
 static __device__ __forceinline__ u64 win64(const u32 (&w)[CH_WIN], int k) {
@@ -220,20 +266,21 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
                                                       ExitRec* __restrict__ exit_tbl, const TileEntry* __restrict__ tile_entry,
                                                       RunRec* __restrict__ run_tbl, u32* __restrict__ otile_first_run,
                                                       const PageDyn* __restrict__ page_dyn) {
-    constexpr u32 E = KIND == KIND_LEVELS ? CH_E_LEVELS : CH_E_STRINGS;
+    static_assert(KIND != KIND_STRINGS, "strings have their own chain kernels");
+    constexpr u32 E = CH_E_LEVELS;
+    constexpr u32 OTK = KIND == KIND_SNAPPY ? SN_T : OT;  // output bytes per tile of the kernel that consumes the records
     constexpr u32 MEMO = CH_SUB * 65;
     // memo per start: exit position, elements passed, and (levels) level values passed.  Levels keep
     // {exit, values} in one 8-byte entry so that a lookup is a single LDS read.
-    __shared__ u64 m_tv[KIND == KIND_LEVELS ? MEMO : 1];
-    __shared__ __attribute__((aligned(16))) u32 m_tgt[KIND == KIND_LEVELS ? 1 : MEMO];
+    __shared__ u64 m_tv[MEMO];
     __shared__ unsigned short m_cnt[MEMO];
     auto memo_get = [&](u32 mi, u32& tgt, u32& val) {
-        if (KIND == KIND_LEVELS) { const u64 e = m_tv[mi]; tgt = (u32)e; val = (u32)(e >> 32); }
-        else { tgt = m_tgt[mi]; val = 0; }
+        const u64 e = m_tv[mi];
+        tgt = (u32)e;
+        val = (u32)(e >> 32);
     };
     auto memo_put = [&](u32 mi, u32 tgt, u32 val) {
-        if (KIND == KIND_LEVELS) m_tv[mi] = (u64)tgt | ((u64)val << 32);
-        else m_tgt[mi] = tgt;
+        m_tv[mi] = (u64)tgt | ((u64)val << 32);
     };
     __shared__ u32 e_pos[MARK ? 64 : 1], e_cnt[MARK ? 64 : 1];
     __shared__ u64 e_val[MARK ? 64 : 1];
@@ -327,18 +374,18 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
 
     // ---- sweep 1: every start of my sub-tile learns where its chain leaves the sub-tile.  The marking
     // pass keeps each start's own step (next start, values, record) in registers for the replay below.
-    u32 st_nxt[MARK ? CH_SUB : 1], st_val[MARK && KIND == KIND_LEVELS ? CH_SUB : 1], st_info[MARK && KIND == KIND_LEVELS ? CH_SUB : 1];
+    u32 st_nxt[MARK ? CH_SUB : 1], st_val[MARK ? CH_SUB : 1], st_info[MARK ? CH_SUB : 1];
 #pragma unroll
     for (int k = CH_SUB - 1; k >= 0; k--) {
         const u32 p = sub_lo + k;
         const bool valid = p < L;
         u32 nxt, vals = 0;
-        if (KIND == KIND_LEVELS) {
+        {
             u32 info;
             const u32 xlo = win32(w, k), xhi = win32(w, k + 4);
-            rle_step_w32(xlo, xhi, p, L, R.width, nxt, vals, info);
+            elem_step_w32<KIND>(xlo, xhi, p, L, R.width, nxt, vals, info);
             if (MARK) {
-                if (!(info & 1) && R.width <= 8) {
+                if (KIND == KIND_LEVELS && !(info & 1) && R.width <= 8) {
                     // RLE run of a narrow level: the record carries the value itself (width 0: value 0)
                     const u32 vp = info >> 1, d = vp - p;
                     u32 val = 0;
@@ -348,11 +395,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
                         val = d < 4 ? (xlo >> (8 * d)) & 0xFF : d < 8 ? (xhi >> (8 * (d - 4))) & 0xFF : b8;
                     info = val << 1;
                 }
-                if ((info & 1) && R.width == 0) info = 0;  // width 0 bit-packed groups are runs of zeros
+                if (KIND == KIND_LEVELS && (info & 1) && R.width == 0) info = 0;  // width 0 bit-packed groups are runs of zeros
                 st_val[k] = vals;
                 st_info[k] = info;
             }
-        } else str_step_win(win32(w, k), p, L, nxt);
+        }
         if (!valid) nxt = ERR_POS;
         if (MARK) st_nxt[k] = nxt;
         // a step that lands on a later start of this sub-tile takes over that start's memoised answer
@@ -426,7 +473,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
             ExitRec x;
             x.tgt = ht[i];
             x.cnt = hc[i];
-            x.vals = KIND == KIND_LEVELS ? hv[i] : 0;
+            x.vals = hv[i];
             exit_tbl[(u64)tile * E + (u32)i * 64 + lane] = x;
         }
         return;
@@ -449,101 +496,27 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
     __syncthreads();
     // ---- every lane replays its sub-tile from its true entry: one record per true element
     u32 q = e_pos[lane];
-    if (KIND == KIND_LEVELS && q == ERR_POS) return;
+    if (q == ERR_POS) return;
     u32 rank = e_cnt[lane];  // index of the element within the region
     // levels: index of the run's first level value, clamped to the page's value count (32-bit from here on)
     const u32 n_out = (u32)R.n_out;
     u32 o = e_val[lane] < n_out ? (u32)e_val[lane] : n_out;
     RunRec* const runs = run_tbl + R.run_base;
     u32* const ofr = otile_first_run + R.otile_base;
-    int32_t* offs = nullptr;
-    u32 cbase = 0;
-    if (KIND == KIND_STRINGS) {
-        const PageDyn pd = page_dyn[R.page];
-        offs = (int32_t*)R.out + pd.val_off;
-        cbase = (u32)pd.char_off;  // offsets are int32: a chunk holds less than 2^31 chars
-    }
-    u32 smask = 0, last_q = 0, last_nxt = 0;  // strings: true starts of my sub-tile; the last of them
 #pragma unroll
     for (int k = 0; k < (int)CH_SUB; k++) {
         if (q == sub_lo + k && q < L) {
-            if (KIND == KIND_LEVELS) {
-                const u32 vals = st_val[k];
-                RunRec rr;
-                rr.out_off = o;
-                rr.info = st_info[k];
-                runs[rank] = rr;
-                const u32 oe = vals < n_out - o ? o + vals : n_out;
-                // which output tiles start inside this run
-                for (u32 t = (o + OT - 1) / OT; t * OT < oe; t++) ofr[t] = rank;
-                o = oe;
-            } else {
-                // string `rank` of the page starts at q: its chars begin at q + 4; every earlier string of
-                // the page contributed 4 length bytes.  A page never holds more values than levels.
-                if (rank < n_out) offs[rank] = (int32_t)(cbase + q - 4u * rank);
-                smask |= 1u << k;
-                last_q = q;
-                last_nxt = st_nxt[k];
-            }
+            const u32 vals = st_val[k];
+            RunRec rr;
+            rr.out_off = o;
+            rr.info = st_info[k];
+            runs[rank] = rr;
+            const u32 oe = vals < n_out - o ? o + vals : n_out;
+            // which output tiles start inside this run
+            for (u32 t = (o + OTK - 1) / OTK; t * OTK < oe; t++) ofr[t] = rank;
+            o = oe;
             rank++;
             q = st_nxt[k];
-        }
-    }
-    if (KIND == KIND_STRINGS) {
-        // ---- chars.  The tile owns the strings that start in it.  Every byte of the tile from the true
-        // entry on is either one of their 4 length bytes or one of their chars, and the chars are dense in
-        // the output: char byte number i of the tile goes to chars[g0 + i].  They are compacted through
-        // LDS (the memo table is dead by now) and leave as aligned 16-byte stores; the part of the last
-        // string that lies beyond the tile is copied by the whole wave afterwards.
-        u32 prev = __shfl_up(smask, 1);  // every lane takes part: a masked-off lane would hand its neighbour 0
-        if (lane == 0) prev = 0;
-        const u32 lenmask = smask | (smask << 1) | (smask << 2) | (smask << 3) | ((prev >> 29) & 1) | (((prev >> 30) & 1) * 3) |
-                            (((prev >> 31) & 1) * 7);
-        const u32 lim = te < L ? te : L;
-        const u32 k_lo = ent.pos <= sub_lo ? 0 : ent.pos >= sub_hi ? 32 : ent.pos - sub_lo;
-        const u32 k_hi = lim >= sub_hi ? 32 : lim <= sub_lo ? 0 : lim - sub_lo;
-        u32 own = k_lo >= 32 ? 0 : 0xFFFFFFFFu << k_lo;
-        if (k_hi < 32) own &= (1u << k_hi) - 1;
-        const u32 charmask = own & ~lenmask;
-        // one scan for both counts: chars in the low half, starts in the high half (each <= 2048)
-        const u32 mine = __popc(charmask) | (__popc(smask) << 16);
-        u32 incl = mine;
-        for (int d = 1; d < 64; d <<= 1) {
-            const u32 t = __shfl_up(incl, d);
-            if (lane >= (u32)d) incl += t;
-        }
-        const u32 total = __shfl(incl, 63);
-        const u32 n_chars = total & 0xFFFF, n_starts = total >> 16;
-        const u32 pc = (incl - mine) & 0xFFFF;
-        const u32 g0 = cbase + ent.pos - 4u * ent.cnt;  // chars index of the tile's first char
-        u8* const cdst = R.out2 + g0;
-        const u32 pad = (u32)((uintptr_t)cdst & 15);
-        u8* const stg = (u8*)m_tgt;
-#pragma unroll
-        for (int k = 0; k < (int)CH_SUB; k++)
-            if ((charmask >> k) & 1) stg[pad + pc + __popc(charmask & ((1u << k) - 1))] = (u8)(w[k >> 2] >> (8 * (k & 3)));
-        __syncthreads();
-        const u32 n_stg = pad + n_chars;
-        for (u32 c0 = lane * 16; c0 < n_stg; c0 += 64 * 16) {
-            if (c0 >= pad && c0 + 16 <= n_stg) *(u32x4*)(cdst - pad + c0) = *(const u32x4*)(stg + c0);
-            else for (u32 b = c0 < pad ? pad : c0; b < c0 + 16 && b < n_stg; b++) cdst[b - pad] = stg[b];
-        }
-        // the last string of the tile may run past the tile: its remaining chars follow directly
-        const u64 has = __ballot(smask != 0);
-        if (has) {
-            const int hl = 63 - __builtin_clzll(has);
-            const u32 lq = __shfl(last_q, hl), ln = __shfl(last_nxt, hl);
-            if (ln != ERR_POS && ln > lim) {
-                const u32 s_lo = lq + 4 > lim ? lq + 4 : lim;
-                const u8* sp = rsrc + s_lo;
-                u8* dp = cdst + n_chars;  // == chars + cbase + s_lo - 4 * (ent.cnt + n_starts)
-                const u32 n = ln - s_lo;
-                for (u32 c0 = lane * 16; c0 < n; c0 += 64 * 16) {
-                    if (c0 + 16 <= n) *(u32x4_u*)(dp + c0) = *(const u32x4_u*)(sp + c0);
-                    else for (u32 b = c0; b < n; b++) dp[b] = sp[b];
-                }
-                (void)n_starts;
-            }
         }
     }
 }
@@ -764,7 +737,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
 template <int KIND>
 static __device__ __forceinline__ u32 hop_tile(const Region& R, const GlobalBytes& B, const ExitRec* __restrict__ exit_tbl,
                                                u32 p, u32& cnt, u64& vals) {
-    constexpr u32 E = KIND == KIND_LEVELS ? CH_E_LEVELS : CH_E_STRINGS;
+    constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     const u32 L = R.len, t = p / CH_T, off = p % CH_T;
     if (off < E) {
         const ExitRec x = exit_tbl[(u64)(R.tile_base + t) * E + off];
@@ -776,8 +749,8 @@ static __device__ __forceinline__ u32 hop_tile(const Region& R, const GlobalByte
     u32 q = p;
     while (q < tend) {
         u32 nxt; u64 v = 0;
-        if (KIND == KIND_LEVELS) { u32 info; rle_step(B, q, L, R.width, nxt, v, info); }
-        else str_step(B, q, L, nxt);
+        if (KIND == KIND_STRINGS) str_step(B, q, L, nxt);
+        else { u32 info; elem_step<KIND>(B, q, L, R.width, nxt, v, info); }
         cnt++; vals += v;
         q = nxt;
     }
@@ -788,7 +761,7 @@ template <int KIND>
 __global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                      const u32* __restrict__ group_prefix, u32 n_regions,
                                                      const ExitRec* __restrict__ exit_tbl, ExitRec* __restrict__ gexit) {
-    constexpr u32 E = KIND == KIND_LEVELS ? CH_E_LEVELS : CH_E_STRINGS;
+    constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     constexpr u32 G = KIND == KIND_LEVELS ? CH_G_LEVELS : CH_G_STRINGS;
     const u32 group = blockIdx.x / (E / 64);
     const u32 i = (blockIdx.x % (E / 64)) * 64 + threadIdx.x;  // entry offset into the group's first tile
@@ -818,7 +791,7 @@ __global__ void k_chain_resolve(const u8* __restrict__ src_base, const Region* _
                                 const ExitRec* __restrict__ exit_tbl, const ExitRec* __restrict__ gexit,
                                 TileEntry* __restrict__ group_entry, RegionTotal* __restrict__ totals,
                                 int* __restrict__ status) {
-    constexpr u32 E = KIND == KIND_LEVELS ? CH_E_LEVELS : CH_E_STRINGS;
+    constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     constexpr u32 G = KIND == KIND_LEVELS ? CH_G_LEVELS : CH_G_STRINGS;
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_regions) return;
@@ -849,6 +822,7 @@ __global__ void k_chain_resolve(const u8* __restrict__ src_base, const Region* _
     totals[r] = tot;
     if (err) set_status(status, ST_CORRUPT, r);
     else if (KIND == KIND_LEVELS && vals < R.n_out) set_status(status, ST_CORRUPT, r);  // defs[:NumValues] out of range
+    else if (KIND == KIND_SNAPPY && vals != R.n_out) set_status(status, ST_CORRUPT, r);  // d != len(dst)
 }
 
 template <int KIND>
@@ -1354,6 +1328,146 @@ __global__ void k_str_check(const Region* __restrict__ regions, u32 n_regions, c
 }
 
 // =====================================================================================
+// k_snappy_tiles — decodes SN_T = 64 KiB of one snappy block's output per workgroup, in LDS, from the
+// element records the chain kernels left (out_off, literal position or copy offset).
+//   1. literals: every wave takes 64 elements at a time and copies their literals one after the other
+//      with all lanes (a 64 KiB literal of incompressible data is just a long copy loop);
+//   2. copies, in windows of 256 elements (one per thread): a copy runs as soon as every byte before
+//      its source end is final, i.e. its source ends at or before the output position of the first
+//      unfinished element; the window repeats until all its copies ran.  A copy is a byte loop in LDS,
+//      so a copy that overlaps its own output (offset < length) repeats its pattern as the format says;
+//   3. the tile leaves as aligned 16-byte stores.
+// The usual encoders (golang/snappy, C++ snappy) compress 64 KiB blocks independently, so no copy reaches
+// across a tile boundary; a stream that does is reported as unsupported rather than decoded wrongly.
+// d < offset (a copy reaching before the start of the output) is ErrCorrupt.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_snappy_tiles(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                                                      const u32* __restrict__ otile_region, const RunRec* __restrict__ run_tbl,
+                                                      const u32* __restrict__ otile_first_run,
+                                                      const RegionTotal* __restrict__ totals, int* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) u8 s_o[SN_T];
+    __shared__ u32 w_out[257], w_info[256];
+    __shared__ u32 s_flag[4];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 ot = blockIdx.x;
+    const u32 ri = otile_region[ot];
+    u32 first = otile_first_run[ot];
+    const u32 nf = otile_first_run[ot + 1];
+    const bool next_same = otile_region[ot + 1] == ri;
+    const Region R = regions[ri];
+    const RegionTotal T = totals[ri];
+    if (first == ERR_POS || T.err || T.vals != R.n_out) return;  // corrupt block: status already set
+    const u32 n_out = (u32)R.n_out;
+    const u32 B = (ot - R.otile_base) * SN_T;
+    const u32 t_hi = B + SN_T < n_out ? B + SN_T : n_out;
+    const u8* rsrc = src_base + R.src_off;
+    const RunRec* runs = run_tbl + R.run_base;
+    u32 last = T.cnt;
+    if (next_same && nf != ERR_POS && nf + 1 < last) last = nf + 1;
+
+    // ---- 1. literals
+    for (u32 base = first + wv * 64; base < last; base += 256) {
+        const u32 e = base + lane;
+        u32 o = 0, oe = 0, info = 1;
+        if (e < last) {
+            const RunRec rr = runs[e];
+            o = rr.out_off; info = rr.info;
+            oe = e + 1 < T.cnt ? runs[e + 1].out_off : n_out;
+        }
+        u64 m = __ballot(e < last && !(info & 1));
+        while (m) {
+            const int l = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const u32 lo_ = __shfl(o, l), hi_ = __shfl(oe, l), sp = __shfl(info, l) >> 1;
+            const u32 lo = lo_ > B ? lo_ : B, hi = hi_ < t_hi ? hi_ : t_hi;  // a literal may straddle tiles
+            if (hi > lo) {
+                const u8* s = rsrc + sp + (lo - lo_);
+                u8* d = s_o + (lo - B);
+                for (u32 k = lane; k < hi - lo; k += 64) d[k] = s[k];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. copies, window by window
+    for (u32 w0 = first; w0 < last; w0 += 256) {
+        const u32 e = w0 + tid;
+        const u32 wn = last - w0 < 256 ? last - w0 : 256;
+        if (tid < wn) {
+            const RunRec rr = runs[e];
+            w_out[tid] = rr.out_off;
+            w_info[tid] = rr.info;
+        }
+        if (tid == 0) w_out[wn] = w0 + wn < T.cnt ? runs[w0 + wn].out_off : n_out;
+        __syncthreads();
+        bool pending = false;
+        u32 o = 0, len = 0, off = 0;
+        if (tid < wn && (w_info[tid] & 1)) {
+            o = w_out[tid];
+            len = w_out[tid + 1] - o;
+            off = w_info[tid] >> 1;
+            pending = true;
+            if (off > o) { set_status(status, ST_CORRUPT, ri); pending = false; }               // d < offset
+            else if (o < B || o + len > t_hi || o - off < B) { set_status(status, ST_UNSUPPORTED, ri); pending = false; }
+        }
+        const u32 src_end = o - off + (len < off ? len : off);
+        for (;;) {
+            // W = output position of the first element of the window that has not run yet
+            const u64 pm = __ballot(pending);
+            if (lane == 0) s_flag[wv] = pm ? (u32)(wv * 64 + __ffsll((unsigned long long)pm) - 1) : 0xFFFFFFFFu;
+            __syncthreads();
+            u32 fp = s_flag[0];
+            fp = s_flag[1] < fp ? s_flag[1] : fp;
+            fp = s_flag[2] < fp ? s_flag[2] : fp;
+            fp = s_flag[3] < fp ? s_flag[3] : fp;
+            if (fp == 0xFFFFFFFFu) break;
+            const u32 W = w_out[fp];
+            if (pending && src_end <= W) {
+                u8* d = s_o + (o - B);
+                for (u32 k = 0; k < len; k++) d[k] = d[(int)k - (int)off];
+                pending = false;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. store (R.out is 16-byte aligned, B is a multiple of 64 KiB)
+    u8* dst = R.out + B;
+    const u32 n = t_hi - B;
+    for (u32 i = tid * 16; i < n; i += 256 * 16) {
+        if (i + 16 <= n) *(u32x4*)(dst + i) = *(const u32x4*)(s_o + i);
+        else for (u32 k = i; k < n; k++) dst[k] = s_o[k];
+    }
+}
+
+// Level block sizes of pages whose payload only exists on the device (decompressed pages): the int32
+// length in front of each hybrid-RLE block (rle.go:161-164), rep block first when the column repeats.
+// sizes[2*i] / sizes[2*i+1] = rep / def block bytes including the 4 length bytes, 0 when absent,
+// -1 when the length is negative or runs past the page.
+__global__ void k_level_block_sizes(const u8* __restrict__ src, const PageRec* __restrict__ pages,
+                                    const ChunkRec* __restrict__ chunks, u32 n_pages, int* __restrict__ sizes) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pages) return;
+    const PageRec P = pages[i];  // val_src_off / val_len = the whole payload here
+    const ChunkRec C = chunks[P.chunk];
+    const u8* p = src + P.val_src_off;
+    u64 l = 0;
+    int out[2] = {0, 0};
+    for (int lv = 0; lv < 2; lv++) {
+        const bool present = lv == 0 ? C.max_rep > 0 : C.max_def > 0;
+        if (!present) continue;
+        if (l + 4 > P.val_len) { out[lv] = -1; break; }
+        const int len = (int)((u32)p[l] | ((u32)p[l + 1] << 8) | ((u32)p[l + 2] << 16) | ((u32)p[l + 3] << 24));
+        if (len < 0 || l + 4 + (u64)len > P.val_len) { out[lv] = -1; break; }
+        out[lv] = len + 4;
+        l += 4 + (u64)len;
+    }
+    sizes[2 * i] = out[0];
+    sizes[2 * i + 1] = out[1];
+}
+
+// =====================================================================================
 // Validity bitmap and per-row offsets.  A row starts at every level with rep == 0 (every level when
 // the column is not repeated); its value offset is the number of def == max_def before it.
 //   k_rows_count   per tile of RT levels: row starts and non-null counts (+ validity words)
@@ -1497,11 +1611,11 @@ hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32
 template <int KIND>
 static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs& a, RunRec* run_tbl, u32* otile_first_run,
                                  const PageDyn* page_dyn, int* status, int phase) {
-    constexpr u32 E = KIND == KIND_LEVELS ? CH_E_LEVELS : CH_E_STRINGS;
+    constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     if (a.n_regions == 0) return hipSuccess;
     if (phase == 0) {
         if (a.n_tiles) {
-            if (KIND == KIND_STRINGS)
+            if constexpr (KIND == KIND_STRINGS)
                 hipLaunchKernelGGL(k_str_exits, dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix,
                                    a.n_regions, a.exit_tbl, (u32x4*)a.str_cp);
             else
@@ -1522,7 +1636,7 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
             LAUNCH_CHECK();
         }
     } else if (a.n_tiles) {
-        if (KIND == KIND_STRINGS)
+        if constexpr (KIND == KIND_STRINGS)
             hipLaunchKernelGGL(k_str_mark, dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix, a.n_regions,
                                a.tile_entry, (const u32x4*)a.str_cp, page_dyn);
         else
@@ -1535,8 +1649,9 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
 
 hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs& a, RunRec* run_tbl, u32* otile_first_run,
                         const PageDyn* page_dyn, int* status, int phase) {
-    return kind == KIND_LEVELS ? launch_chain_t<KIND_LEVELS>(st, src, a, run_tbl, otile_first_run, page_dyn, status, phase)
-                               : launch_chain_t<KIND_STRINGS>(st, src, a, run_tbl, otile_first_run, page_dyn, status, phase);
+    if (kind == KIND_LEVELS) return launch_chain_t<KIND_LEVELS>(st, src, a, run_tbl, otile_first_run, page_dyn, status, phase);
+    if (kind == KIND_SNAPPY) return launch_chain_t<KIND_SNAPPY>(st, src, a, run_tbl, otile_first_run, page_dyn, status, phase);
+    return launch_chain_t<KIND_STRINGS>(st, src, a, run_tbl, otile_first_run, page_dyn, status, phase);
 }
 
 hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_region,
@@ -1598,6 +1713,23 @@ hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_
         hipLaunchKernelGGL((k_rows<true>), dim3(n_rtiles), dim3(256), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles);
         LAUNCH_CHECK();
     }
+    return hipSuccess;
+}
+
+hipError_t launch_snappy_tiles(hipStream_t st, const u8* src, const Region* regions, const u32* otile_region, u32 n_otiles,
+                               const RunRec* run_tbl, const u32* otile_first_run, const RegionTotal* totals, int* status) {
+    if (n_otiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_snappy_tiles, dim3(n_otiles), dim3(256), 0, st, src, regions, otile_region, run_tbl, otile_first_run,
+                       totals, status);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_level_block_sizes(hipStream_t st, const u8* src, const PageRec* pages, const ChunkRec* chunks, u32 n_pages,
+                                    int* sizes) {
+    if (n_pages == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_level_block_sizes, dim3((n_pages + 255) / 256), dim3(256), 0, st, src, pages, chunks, n_pages, sizes);
+    LAUNCH_CHECK();
     return hipSuccess;
 }
 
