@@ -49,12 +49,14 @@ typedef struct {
     int32_t n_pages;
     int32_t column;      /* leaf index in the file schema (informational; set by pqd_file_descriptors) */
     int64_t num_values;  /* parquet.Page.N: levels in the chunk, nulls included (parquet.go:336) */
+    int32_t codec;       /* parquet.Page.Codec (parquet.go:32): 0 UNCOMPRESSED, 1 SNAPPY; others are not decoded */
+    int32_t reserved;
 } pqd_chunk_desc;
 
 /* One data page as the reference's page loops see it (fields.go:114-135, 275-317). */
 typedef struct {
     int64_t src_off;     /* offset of the page payload (first byte after the thrift PageHeader) */
-    int32_t payload_len; /* PageHeader.uncompressed_page_size */
+    int32_t payload_len; /* bytes pageData reads: uncompressed_page_size, or compressed_page_size under a codec */
     int32_t num_values;  /* DataPageHeader.num_values */
     int32_t rep_bytes;   /* size of the repetition-level block incl. its 4-byte length, 0 if none; -1 = read it from src */
     int32_t def_bytes;   /* same for definition levels */
@@ -101,6 +103,7 @@ void pqd_host_free(pqd_ctx* ctx, void* p);
 void* pqd_device_alloc(pqd_ctx* ctx, size_t bytes);
 void pqd_device_free(pqd_ctx* ctx, void* p);
 int pqd_copy_to_device(pqd_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+int pqd_copy_to_host(pqd_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
 
 /* ---- decode: replaces the bodies of the six generated Field.Read methods -------------------
  * (cmd/parquetgen/gen/template_required.go:25-35, template_optional.go:42-52, template_string.go:41-60,
@@ -157,6 +160,30 @@ int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
 int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block, size_t block_len,
                    int out_elem_size, void* out_host, size_t max_values, int64_t* n_decoded);
 
+/* ---- SNAPPY pages: pageData's SNAPPY arm (fields.go:361-371, snappy.Decode of golang/snappy) ------
+ * pqd_decode handles SNAPPY chunks by itself; these are its steps for callers that keep the file on
+ * the device.  A block is one page payload in snappy's raw block format (uvarint decoded length, then
+ * literal / copy elements). */
+typedef struct {
+    int64_t src_off;     /* in: first byte of the compressed page payload */
+    int64_t comp_len;    /* in: PageHeader.compressed_page_size */
+    int64_t dst_off;     /* in (decode): where the decoded bytes go; base + dst_off must be 16-byte aligned */
+    int64_t decoded_len; /* out of pqd_snappy_sizes: the length the preamble declares (decodedLen) */
+    int32_t hdr_len;     /* out of pqd_snappy_sizes: bytes of the preamble */
+    int32_t reserved;
+} pqd_snappy_block;
+/* Host only: reads the uvarint preamble of every block.  PQD_E_CORRUPT as snappy.ErrCorrupt. */
+int pqd_snappy_sizes(const void* src_host, size_t src_len, pqd_snappy_block* blocks, size_t n);
+/* Decodes n blocks from device memory to device memory and waits for them.  PQD_E_CORRUPT where
+ * snappy.Decode returns ErrCorrupt; PQD_E_UNSUPPORTED for a stream whose copies reach across a 64 KiB
+ * boundary of the output (no encoder the reference links produces one). */
+int pqd_snappy_decode(pqd_ctx* ctx, const pqd_snappy_block* blocks, size_t n, const void* src_device, size_t src_len,
+                      void* dst_device, size_t dst_len);
+/* Fills rep_bytes / def_bytes of pages whose payload exists only on the device (decoded pages): the
+ * int32 length in front of each level block (rle.go:161-164, fields.go:295-309). */
+int pqd_level_block_sizes(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks, pqd_page_desc* pages, size_t n_pages,
+                          const void* src_device, size_t src_len);
+
 /* ---- file walk: the host-side prerequisite (parquet.go:349-378 ReadMetaData/PageHeader,
  * parquet.go:322-346 Pages, template.go:320-351 readRowGroup's chunk order) ------------------- */
 typedef struct pqd_file pqd_file;
@@ -192,7 +219,7 @@ int64_t pqd_file_num_pages(const pqd_file* f);
  * out = {type, uncompressed_page_size, compressed_page_size, num_values, encoding,
  *        definition_level_encoding, repetition_level_encoding, header length in bytes}. */
 int pqd_file_page_header(const pqd_file* f, int64_t page, int32_t out[8], int64_t* header_pos);
-/* CompressionCodec of a column chunk (0 = UNCOMPRESSED; others are walked but not decoded). */
+/* CompressionCodec of a column chunk (0 UNCOMPRESSED, 1 SNAPPY; others are walked but not decoded). */
 int pqd_file_chunk_codec(const pqd_file* f, int32_t rg, int32_t chunk);
 /* What Metadata.Pages (parquet.go:322-346) hands the Field for one chunk, plus where the walk found it:
  * out = {leaf column index, ColumnMetaData.num_values (Page.N), total_compressed_size (Page.Size),

@@ -25,7 +25,12 @@ BOOLEAN, INT32, INT64, INT96, FLOAT, DOUBLE, BYTE_ARRAY, FIXED_LEN_BYTE_ARRAY = 
 class ChunkDesc(C.Structure):
     _fields_ = [("phys_type", C.c_int32), ("max_def", C.c_int32), ("max_rep", C.c_int32),
                 ("first_page", C.c_int32), ("n_pages", C.c_int32), ("column", C.c_int32),
-                ("num_values", C.c_int64)]
+                ("num_values", C.c_int64), ("codec", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SnappyBlock(C.Structure):
+    _fields_ = [("src_off", C.c_int64), ("comp_len", C.c_int64), ("dst_off", C.c_int64), ("decoded_len", C.c_int64),
+                ("hdr_len", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PageDesc(C.Structure):
@@ -54,6 +59,7 @@ DECODE_SYMBOLS = {
     "pqd_device_alloc": (_P, [_P, C.c_size_t]),
     "pqd_device_free": (None, [_P, _P]),
     "pqd_copy_to_device": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "pqd_copy_to_host": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "pqd_plan_create": (C.c_int, [_P, C.POINTER(ChunkDesc), C.c_size_t, C.POINTER(PageDesc), C.c_size_t,
                                   _P, C.c_size_t, C.POINTER(_P)]),
     "pqd_plan_destroy": (None, [_P]),
@@ -68,6 +74,9 @@ DECODE_SYMBOLS = {
     "pqd_decode": (C.c_int, [_P, C.POINTER(ChunkDesc), C.c_size_t, C.POINTER(PageDesc), C.c_size_t,
                              _P, C.c_size_t, C.POINTER(_P)]),
     "pqd_rle_decode": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int, _P, C.c_size_t, C.POINTER(C.c_int64)]),
+    "pqd_snappy_sizes": (C.c_int, [_P, C.c_size_t, C.POINTER(SnappyBlock), C.c_size_t]),
+    "pqd_snappy_decode": (C.c_int, [_P, C.POINTER(SnappyBlock), C.c_size_t, _P, C.c_size_t, _P, C.c_size_t]),
+    "pqd_level_block_sizes": (C.c_int, [_P, C.POINTER(ChunkDesc), C.c_size_t, C.POINTER(PageDesc), C.c_size_t, _P, C.c_size_t]),
     "pqd_file_open": (C.c_int, [_P, C.c_size_t, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     "pqd_file_close": (None, [_P]),
     "pqd_file_num_rows": (C.c_int64, [_P]),
@@ -85,6 +94,8 @@ DECODE_SYMBOLS = {
 }
 
 SYNTH_SYMBOLS = {
+    "pqw_set_codec": (C.c_int, [_P, C.c_int]),
+    "pqw_snappy_compress": (C.c_int64, [_P, C.c_int64, _P, C.c_int64]),
     "pqw_create": (_P, [C.c_int]),
     "pqw_destroy": (None, [_P]),
     "pqw_add_column": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]),

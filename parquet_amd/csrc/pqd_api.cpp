@@ -180,6 +180,14 @@ int pqd_copy_to_device(pqd_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return PQD_OK;
 }
 
+int pqd_copy_to_host(pqd_ctx* ctx, void* dst, const void* src_device, size_t bytes) {
+    if (!ctx || !dst || !src_device) return PQD_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PQD_OK;
+}
+
 void pqd_plan_destroy(pqd_plan* pl) {
     if (!pl) return;
     (void)hipSetDevice(pl->ctx->device);
@@ -223,6 +231,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         case PQD_BOOLEAN: case PQD_BYTE_ARRAY: break;
         default: return fail(ctx, PQD_E_UNSUPPORTED, "unsupported physical type");
         }
+        if (cd.codec != 0)
+            return fail(ctx, PQD_E_UNSUPPORTED, "compressed chunk: its pages must be decoded first (pqd_decode does it for SNAPPY)");
         if (cd.max_def < 0 || cd.max_def > 255 || cd.max_rep < 0 || cd.max_rep > 255 || cd.max_rep > cd.max_def)
             return fail(ctx, PQD_E_UNSUPPORTED, "max levels out of range");
         if (cd.first_page < 0 || cd.n_pages < 0 || (size_t)cd.first_page + (size_t)cd.n_pages > n_pages || cd.num_values < 0)
@@ -698,13 +708,66 @@ int64_t pqd_plan_fetch(pqd_plan* pl, size_t c, pqd_output which, void* dst, size
 
 int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks, const pqd_page_desc* pages, size_t n_pages,
                const void* src_host, size_t src_len, pqd_plan** out) {
-    if (!ctx || !out || !src_host) return PQD_E_ARG;
+    if (!ctx || !out || !src_host || (!chunks && n_chunks) || (!pages && n_pages)) return PQD_E_ARG;
+    // SNAPPY chunks: their pages are decoded on the device into an area behind the file bytes, and the
+    // page decoder then reads them there like uncompressed pages (pageData, fields.go:358-402).
+    std::vector<pqd_chunk_desc> cv(chunks, chunks + n_chunks);
+    std::vector<pqd_page_desc> pv(pages, pages + n_pages);
+    std::vector<pqd_snappy_block> blocks;
+    std::vector<size_t> block_page;
+    for (size_t c = 0; c < n_chunks; c++) {
+        if (cv[c].codec == 0) continue;
+        if (cv[c].codec != 1) return fail(ctx, PQD_E_UNSUPPORTED, "codec other than UNCOMPRESSED and SNAPPY");
+        if (cv[c].first_page < 0 || cv[c].n_pages < 0 || (size_t)cv[c].first_page + (size_t)cv[c].n_pages > n_pages)
+            return fail(ctx, PQD_E_ARG, "chunk page range out of bounds");
+        for (int k = 0; k < cv[c].n_pages; k++) {
+            const size_t pi = (size_t)cv[c].first_page + k;
+            pqd_snappy_block b;
+            memset(&b, 0, sizeof b);
+            b.src_off = pv[pi].src_off;
+            b.comp_len = pv[pi].payload_len;
+            blocks.push_back(b);
+            block_page.push_back(pi);
+        }
+        cv[c].codec = 0;
+    }
+    const size_t file_area = align_up(src_len + 64, 256);
+    size_t total = file_area;
+    if (!blocks.empty()) {
+        int rc = pqd_snappy_sizes(src_host, src_len, blocks.data(), blocks.size());
+        if (rc) return fail(ctx, rc, "bad snappy preamble or page outside the file");
+        for (size_t i = 0; i < blocks.size(); i++) {
+            if (blocks[i].decoded_len > 0x7fffffff) return fail(ctx, PQD_E_UNSUPPORTED, "snappy page of 2 GiB or more");
+            blocks[i].dst_off = (int64_t)(total - file_area);
+            pqd_page_desc& pd = pv[block_page[i]];
+            pd.src_off = (int64_t)total;
+            pd.payload_len = (int32_t)blocks[i].decoded_len;
+            total += align_up((size_t)blocks[i].decoded_len + 16, 256);
+        }
+    }
+    u8* dsrc = (u8*)pqd_device_alloc(ctx, total);
+    if (!dsrc) return fail(ctx, PQD_E_NOMEM, "device allocation for the source failed");
+    int rc = pqd_copy_to_device(ctx, dsrc, src_host, src_len);
+    if (!rc && !blocks.empty()) {
+        rc = pqd_snappy_decode(ctx, blocks.data(), blocks.size(), dsrc, src_len, dsrc + file_area, total - file_area);
+        // the level block sizes of decoded pages can only be read on the device
+        if (!rc) rc = pqd_level_block_sizes(ctx, cv.data(), n_chunks, pv.data(), n_pages, dsrc, total);
+        if (!rc)
+            for (size_t c = 0; c < n_chunks; c++)
+                if (chunks[c].codec == 0)  // pages of uncompressed chunks: sizes come from the host copy as before
+                    for (int k = 0; k < cv[c].n_pages; k++) {
+                        pv[(size_t)cv[c].first_page + k].rep_bytes = pages[(size_t)cv[c].first_page + k].rep_bytes;
+                        pv[(size_t)cv[c].first_page + k].def_bytes = pages[(size_t)cv[c].first_page + k].def_bytes;
+                    }
+    }
     pqd_plan* pl = nullptr;
-    int rc = pqd_plan_create(ctx, chunks, n_chunks, pages, n_pages, src_host, src_len, &pl);
-    if (rc) return rc;
-    pl->owned_src = (u8*)pqd_device_alloc(ctx, src_len);
-    if (!pl->owned_src) { pqd_plan_destroy(pl); return fail(ctx, PQD_E_NOMEM, "device allocation for the source failed"); }
-    if ((rc = pqd_copy_to_device(ctx, pl->owned_src, src_host, src_len)) || (rc = pqd_plan_run(pl, pl->owned_src))) {
+    if (!rc) rc = pqd_plan_create(ctx, cv.data(), n_chunks, pv.data(), n_pages, src_host, total, &pl);
+    if (rc) {
+        pqd_device_free(ctx, dsrc);
+        return rc;
+    }
+    pl->owned_src = dsrc;
+    if ((rc = pqd_plan_run(pl, pl->owned_src))) {
         pqd_plan_destroy(pl);
         return rc;
     }
@@ -784,6 +847,172 @@ int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block_, size_t block_len
                                       (u32*)(A + o_otf), (RegionTotal*)(A + o_tot), nullptr, (PageDyn*)(A + o_pdyn)));
     HIP_TRY(ctx, hipMemcpyAsync(out_host, A + o_out, n_emit * (size_t)esz, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    return PQD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SNAPPY pages (pageData's SNAPPY arm, fields.go:361-371): decompressed on the device into a buffer the
+// page decoder then reads like an uncompressed file.
+int pqd_snappy_sizes(const void* src_host_, size_t src_len, pqd_snappy_block* blocks, size_t n) {
+    if (!src_host_ || (!blocks && n)) return PQD_E_ARG;
+    const u8* src = (const u8*)src_host_;
+    for (size_t i = 0; i < n; i++) {
+        pqd_snappy_block& b = blocks[i];
+        if (b.src_off < 0 || b.comp_len < 0 || (u64)b.src_off + (u64)b.comp_len > src_len) return PQD_E_ARG;
+        // decodedLen: binary.Uvarint, corrupt when it does not fit 32 bits
+        u64 v = 0;
+        unsigned shift = 0;
+        int hdr = 0;
+        for (int64_t k = 0; k < b.comp_len && k < 10; k++) {
+            const u8 c = src[b.src_off + k];
+            if (c < 0x80) {
+                if (k == 9 && c > 1) break;
+                v |= (u64)c << shift;
+                hdr = (int)k + 1;
+                break;
+            }
+            v |= (u64)(c & 0x7f) << shift;
+            shift += 7;
+        }
+        if (hdr == 0 || v > 0xffffffffull) return PQD_E_CORRUPT;
+        b.decoded_len = (int64_t)v;
+        b.hdr_len = hdr;
+    }
+    return PQD_OK;
+}
+
+int pqd_snappy_decode(pqd_ctx* ctx, const pqd_snappy_block* blocks, size_t n, const void* src_device, size_t src_len,
+                      void* dst_device, size_t dst_len) {
+    if (!ctx || (!blocks && n) || !src_device || (!dst_device && dst_len)) return PQD_E_ARG;
+    if (n == 0) return PQD_OK;
+    if (n > 0x7fffffffu) return fail(ctx, PQD_E_ARG, "too many blocks");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<Region> regions(n);
+    std::vector<u32> tile_prefix(1, 0), group_prefix(1, 0), otile_region;
+    u64 run_base = 0, n_otiles = 0;
+    for (size_t i = 0; i < n; i++) {
+        const pqd_snappy_block& b = blocks[i];
+        if (b.src_off < 0 || b.comp_len < 0 || b.hdr_len < 1 || b.hdr_len > b.comp_len || b.decoded_len < 0 || b.dst_off < 0 ||
+            (u64)b.src_off + (u64)b.comp_len > src_len || (u64)b.dst_off + (u64)b.decoded_len > dst_len)
+            return fail(ctx, PQD_E_ARG, "snappy block outside its buffer");
+        if (b.comp_len > 0x7fffffff || b.decoded_len > 0x7fffffff) return fail(ctx, PQD_E_UNSUPPORTED, "snappy block of 2 GiB or more");
+        if ((((uintptr_t)dst_device + (u64)b.dst_off) & 15) != 0) return fail(ctx, PQD_E_ARG, "snappy destination must be 16-byte aligned");
+        Region& R = regions[i];
+        memset(&R, 0, sizeof R);
+        R.src_off = (u64)b.src_off + (u64)b.hdr_len;
+        R.len = (u32)(b.comp_len - b.hdr_len);
+        R.tile_base = tile_prefix.back();
+        R.group_base = group_prefix.back();
+        R.otile_base = (u32)n_otiles;
+        R.run_base = run_base;
+        R.n_out = (u64)b.decoded_len;
+        R.out = (u8*)dst_device + b.dst_off;
+        R.page = (u32)i;
+        R.count_level = ERR_POS;
+        const u64 nt = ((u64)R.len + CH_T - 1) / CH_T, ng = ((u64)R.len + (u64)CH_G_STRINGS * CH_T - 1) / ((u64)CH_G_STRINGS * CH_T);
+        const u64 no = ((u64)b.decoded_len + SN_T - 1) / SN_T;
+        if ((u64)tile_prefix.back() + nt > 0x7fffffffull || n_otiles + no > 0x7fffffffull)
+            return fail(ctx, PQD_E_UNSUPPORTED, "batch too large for 32-bit tile indices");
+        tile_prefix.push_back(tile_prefix.back() + (u32)nt);
+        group_prefix.push_back(group_prefix.back() + (u32)ng);
+        otile_region.insert(otile_region.end(), (size_t)no, (u32)i);
+        n_otiles += no;
+        run_base += R.len;
+    }
+    otile_region.push_back(ERR_POS);
+    const u32 n_tiles = tile_prefix.back(), n_groups = group_prefix.back();
+    ArenaPlan ap;
+    const size_t o_reg = ap.take(n * sizeof(Region));
+    const size_t o_tp = ap.take((n + 1) * 4), o_gp = ap.take((n + 1) * 4), o_otr = ap.take(otile_region.size() * 4);
+    const size_t o_exit = ap.take((size_t)n_tiles * CH_E_LEVELS * sizeof(ExitRec));
+    const size_t o_gexit = ap.take((size_t)n_groups * CH_E_LEVELS * sizeof(ExitRec));
+    const size_t o_tot = ap.take(n * sizeof(RegionTotal));
+    const size_t o_runs = ap.take((size_t)run_base * sizeof(RunRec));
+    const size_t o_ff = ap.total;
+    const size_t o_te = ap.take((size_t)n_tiles * sizeof(TileEntry));
+    const size_t o_ge = ap.take((size_t)n_groups * sizeof(TileEntry));
+    const size_t o_otf = ap.take(((size_t)n_otiles + 1) * 4);
+    const size_t ff_end = ap.total;
+    const size_t o_status = ap.take(16);
+    u8* A = nullptr;
+    hipError_t e = hipMalloc((void**)&A, ap.total);
+    if (e != hipSuccess) return fail(ctx, PQD_E_NOMEM, "hipMalloc of the snappy scratch failed", e);
+    struct Free { u8* p; ~Free() { (void)hipFree(p); } } fr{A};
+    const ChainArgs ca{(Region*)(A + o_reg), (u32*)(A + o_tp), (u32*)(A + o_gp), (u32)n, n_tiles, n_groups, (ExitRec*)(A + o_exit),
+                       (ExitRec*)(A + o_gexit), (TileEntry*)(A + o_te), (TileEntry*)(A + o_ge), (RegionTotal*)(A + o_tot)};
+    HIP_TRY(ctx, hipMemsetAsync(A + o_ff, 0xFF, ff_end - o_ff, st));
+    HIP_TRY(ctx, hipMemsetAsync(A + o_status, 0, 16, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_reg, regions.data(), n * sizeof(Region), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_tp, tile_prefix.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_gp, group_prefix.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_otr, otile_region.data(), otile_region.size() * 4, hipMemcpyHostToDevice, st));
+    const u8* src = (const u8*)src_device;
+    HIP_TRY(ctx, launch_chain(st, KIND_SNAPPY, src, ca, (RunRec*)(A + o_runs), (u32*)(A + o_otf), nullptr, (int*)(A + o_status), 0));
+    HIP_TRY(ctx, launch_chain(st, KIND_SNAPPY, src, ca, (RunRec*)(A + o_runs), (u32*)(A + o_otf), nullptr, (int*)(A + o_status), 1));
+    HIP_TRY(ctx, launch_snappy_tiles(st, src, (Region*)(A + o_reg), (u32*)(A + o_otr), (u32)n_otiles, (RunRec*)(A + o_runs),
+                                     (u32*)(A + o_otf), (RegionTotal*)(A + o_tot), (int*)(A + o_status)));
+    int status[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(status, A + o_status, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (status[0]) {
+        char b[160];
+        snprintf(b, sizeof b, "snappy decode failed: device status %d at block %d%s", status[0], status[1],
+                 status[0] == ST_UNSUPPORTED ? " (a copy reaches across a 64 KiB output block)" : "");
+        ctx->err = b;
+        return map_status(status[0]);
+    }
+    return PQD_OK;
+}
+
+int pqd_level_block_sizes(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks, pqd_page_desc* pages, size_t n_pages,
+                          const void* src_device, size_t src_len) {
+    if (!ctx || (!chunks && n_chunks) || (!pages && n_pages) || !src_device) return PQD_E_ARG;
+    if (n_pages == 0) return PQD_OK;
+    if (n_pages > 0x7fffffffu || n_chunks > 0x7fffffffu) return fail(ctx, PQD_E_ARG, "too many chunks or pages");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<ChunkRec> C(n_chunks);
+    std::vector<PageRec> P(n_pages);
+    std::vector<char> seen(n_pages, 0);
+    for (size_t c = 0; c < n_chunks; c++) {
+        memset(&C[c], 0, sizeof(ChunkRec));
+        C[c].max_def = chunks[c].max_def;
+        C[c].max_rep = chunks[c].max_rep;
+        if (chunks[c].first_page < 0 || chunks[c].n_pages < 0 || (size_t)chunks[c].first_page + (size_t)chunks[c].n_pages > n_pages)
+            return fail(ctx, PQD_E_ARG, "chunk page range out of bounds");
+        for (int k = 0; k < chunks[c].n_pages; k++) {
+            const size_t pi = (size_t)chunks[c].first_page + k;
+            const pqd_page_desc& pd = pages[pi];
+            if (pd.src_off < 0 || pd.payload_len < 0 || (u64)pd.src_off + (u64)pd.payload_len > src_len)
+                return fail(ctx, PQD_E_CORRUPT, "page payload outside the source buffer");
+            memset(&P[pi], 0, sizeof(PageRec));
+            P[pi].val_src_off = (u64)pd.src_off;
+            P[pi].val_len = (u32)pd.payload_len;
+            P[pi].chunk = (u32)c;
+            seen[pi] = 1;
+        }
+    }
+    for (size_t p = 0; p < n_pages; p++)
+        if (!seen[p]) return fail(ctx, PQD_E_ARG, "page not owned by any chunk");
+    ArenaPlan ap;
+    const size_t o_c = ap.take(n_chunks * sizeof(ChunkRec)), o_p = ap.take(n_pages * sizeof(PageRec)), o_s = ap.take(n_pages * 8);
+    u8* A = nullptr;
+    hipError_t e = hipMalloc((void**)&A, ap.total);
+    if (e != hipSuccess) return fail(ctx, PQD_E_NOMEM, "hipMalloc failed", e);
+    struct Free { u8* p; ~Free() { (void)hipFree(p); } } fr{A};
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_c, C.data(), n_chunks * sizeof(ChunkRec), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_p, P.data(), n_pages * sizeof(PageRec), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, launch_level_block_sizes(st, (const u8*)src_device, (PageRec*)(A + o_p), (ChunkRec*)(A + o_c), (u32)n_pages,
+                                          (int*)(A + o_s)));
+    std::vector<int> sizes(n_pages * 2);
+    HIP_TRY(ctx, hipMemcpyAsync(sizes.data(), A + o_s, n_pages * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (size_t p = 0; p < n_pages; p++) {
+        if (sizes[2 * p] < 0 || sizes[2 * p + 1] < 0) return fail(ctx, PQD_E_CORRUPT, "level block runs past the page payload");
+        pages[p].rep_bytes = sizes[2 * p];
+        pages[p].def_bytes = sizes[2 * p + 1];
+    }
     return PQD_OK;
 }
 

@@ -359,7 +359,7 @@ int pqd_file_descriptors(pqd_file* f, int32_t rg_first, int32_t rg_count,
     f->out_pages.clear();
     for (int32_t g = rg_first; g < rg_first + rg_count; g++) {
         for (const ChunkMeta& ch : f->row_groups[g].chunks) {
-            if (ch.codec != 0 || ch.dictionary_page_offset > 0) return PQD_E_UNSUPPORTED;
+            if ((ch.codec != 0 && ch.codec != 1) || ch.dictionary_page_offset > 0) return PQD_E_UNSUPPORTED;
             const pqd_column_info& ci = f->columns[ch.col].info;
             pqd_chunk_desc cd;
             cd.phys_type = ci.phys_type;
@@ -369,6 +369,8 @@ int pqd_file_descriptors(pqd_file* f, int32_t rg_first, int32_t rg_count,
             cd.n_pages = (int32_t)ch.n_pages;
             cd.column = ch.col;
             cd.num_values = ch.num_values;
+            cd.codec = ch.codec;
+            cd.reserved = 0;
             f->out_chunks.push_back(cd);
             for (int64_t p = 0; p < ch.n_pages; p++) {
                 const PageHdr& h = f->page_headers[ch.first_page + p];

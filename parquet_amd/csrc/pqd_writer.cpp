@@ -105,6 +105,7 @@ struct pqw {
     std::vector<uint8_t> buf;
     std::vector<Col> cols;
     int stats_mode = 1;
+    int codec = 0;  // 0 UNCOMPRESSED, 1 SNAPPY (every page of the file)
     bool in_rg = false;
     std::vector<ChunkAcc> cur;
     struct RG { int64_t rows; std::vector<ChunkAcc> chunks; };
@@ -116,6 +117,63 @@ struct pqw {
 
 namespace {
 
+// A small greedy snappy compressor (raw block format): 64 KiB blocks compressed independently, 4-byte
+// hash matches, copy elements with 1- and 2-byte offsets.  It exists so that the synthetic files can carry
+// SNAPPY pages like the files the reference writes by default (fields.go:69,180); any snappy decoder
+// reads its output.
+void snappy_literal(const uint8_t* p, size_t n, std::vector<uint8_t>& out) {
+    if (n == 0) return;
+    const size_t x = n - 1;
+    if (x < 60) out.push_back((uint8_t)(x << 2));
+    else if (x < 256) { out.push_back(60 << 2); out.push_back((uint8_t)x); }
+    else if (x < 65536) { out.push_back(61 << 2); out.push_back((uint8_t)x); out.push_back((uint8_t)(x >> 8)); }
+    else { out.push_back(62 << 2); out.push_back((uint8_t)x); out.push_back((uint8_t)(x >> 8)); out.push_back((uint8_t)(x >> 16)); }
+    out.insert(out.end(), p, p + n);
+}
+void snappy_compress(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
+    for (size_t v = n;;) {  // uvarint preamble
+        if (v < 0x80) { out.push_back((uint8_t)v); break; }
+        out.push_back((uint8_t)(v | 0x80));
+        v >>= 7;
+    }
+    std::vector<int32_t> table(1 << 14);
+    for (size_t b0 = 0; b0 < n; b0 += 65536) {
+        const uint8_t* p = in + b0;
+        const size_t len = std::min<size_t>(65536, n - b0);
+        std::fill(table.begin(), table.end(), -1);
+        size_t i = 0, lit = 0;
+        while (i + 4 <= len) {
+            uint32_t x;
+            memcpy(&x, p + i, 4);
+            const uint32_t h = (x * 0x1e35a7bdu) >> 18;
+            const int32_t cand = table[h];
+            table[h] = (int32_t)i;
+            uint32_t y = 0;
+            if (cand >= 0) memcpy(&y, p + cand, 4);
+            if (cand < 0 || x != y) { i++; continue; }
+            snappy_literal(p + lit, i - lit, out);
+            size_t ml = 4;
+            while (i + ml < len && p[cand + ml] == p[i + ml]) ml++;
+            const size_t off = i - (size_t)cand;
+            i += ml;
+            lit = i;
+            while (ml > 0) {
+                const size_t l = ml > 64 ? (ml - 64 < 4 ? 60 : 64) : ml;
+                if (l >= 4 && l <= 11 && off < 2048) {
+                    out.push_back((uint8_t)(1 | ((l - 4) << 2) | ((off >> 8) << 5)));
+                    out.push_back((uint8_t)off);
+                } else {
+                    out.push_back((uint8_t)(2 | ((l - 1) << 2)));
+                    out.push_back((uint8_t)off);
+                    out.push_back((uint8_t)(off >> 8));
+                }
+                ml -= l;
+            }
+        }
+        snappy_literal(p + lit, len - lit, out);
+    }
+}
+
 template <typename T>
 void minmax_bytes(const void* vals, int64_t n, uint8_t* mn, uint8_t* mx) {
     const T* v = (const T*)vals;
@@ -125,13 +183,13 @@ void minmax_bytes(const void* vals, int64_t n, uint8_t* mn, uint8_t* mx) {
     memcpy(mx, &hi, sizeof(T));
 }
 
-void write_page_header(pqw* w, const Col& c, size_t payload, int64_t num_values, int64_t nulls,
+void write_page_header(pqw* w, const Col& c, size_t payload, size_t stored, int64_t num_values, int64_t nulls,
                        const uint8_t* mn, const uint8_t* mx, int mlen, std::vector<uint8_t>& out) {
     th::Writer t;
     t.struct_begin();
     t.i32(1, 0);  // DATA_PAGE
-    t.i32(2, (int32_t)payload);
-    t.i32(3, (int32_t)payload);
+    t.i32(2, (int32_t)payload);  // uncompressed_page_size
+    t.i32(3, (int32_t)stored);   // compressed_page_size
     t.struct_field_begin(5);
     t.i32(1, (int32_t)num_values);
     t.i32(2, 0);  // PLAIN
@@ -152,8 +210,16 @@ int emit_page(pqw* w, int col, const std::vector<uint8_t>& payload, int64_t num_
               const uint8_t* mn, const uint8_t* mx, int mlen) {
     if (payload.size() > 0x7fffffffu) return -1;
     size_t before = w->buf.size();
-    write_page_header(w, w->cols[col], payload.size(), num_values, nulls, mn, mx, mlen, w->buf);
-    w->buf.insert(w->buf.end(), payload.begin(), payload.end());
+    if (w->codec == 1) {
+        std::vector<uint8_t> comp;
+        snappy_compress(payload.data(), payload.size(), comp);
+        if (comp.size() > 0x7fffffffu) return -1;
+        write_page_header(w, w->cols[col], payload.size(), comp.size(), num_values, nulls, mn, mx, mlen, w->buf);
+        w->buf.insert(w->buf.end(), comp.begin(), comp.end());
+    } else {
+        write_page_header(w, w->cols[col], payload.size(), payload.size(), num_values, nulls, mn, mx, mlen, w->buf);
+        w->buf.insert(w->buf.end(), payload.begin(), payload.end());
+    }
     ChunkAcc& a = w->cur[col];
     a.used = true;
     a.num_values += num_values;
@@ -172,6 +238,21 @@ pqw* pqw_create(int stats_mode) {
     return w;
 }
 void pqw_destroy(pqw* w) { delete w; }
+int pqw_set_codec(pqw* w, int codec) {
+    if (!w || (codec != 0 && codec != 1) || !w->rgs.empty() || w->in_rg) return -1;
+    w->codec = codec;
+    return 0;
+}
+
+// Test helper: the compressor on its own.
+int64_t pqw_snappy_compress(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap) {
+    std::vector<uint8_t> b;
+    snappy_compress(in, (size_t)n, b);
+    if ((int64_t)b.size() > cap) return -(int64_t)b.size();
+    memcpy(out, b.data(), b.size());
+    return (int64_t)b.size();
+}
+
 int pqw_reserve(pqw* w, int64_t bytes) {
     if (!w || bytes < 0) return -1;
     w->buf.reserve((size_t)bytes);
@@ -359,7 +440,7 @@ int pqw_finish(pqw* w) {
             t.raw_i32(0);                   // encodings = [PLAIN]
             t.list_begin(3, th::T_BINARY, c.parts.size());
             for (const auto& p : c.parts) t.raw_binary(p.data(), p.size());
-            t.i32(4, 0);                    // UNCOMPRESSED
+            t.i32(4, w->codec);             // CompressionCodec
             t.i64(5, ch.num_values);
             t.i64(6, ch.total_size);
             t.i64(7, ch.total_size);

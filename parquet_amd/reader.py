@@ -232,6 +232,41 @@ def decode_host(ctx, chunks, n_chunks, pages, n_pages, src_addr, src_len):
     return pl
 
 
+def snappy_decode_blocks(ctx, blocks):
+    """snappy.Decode of several raw-format blocks on the device (pqd_snappy_sizes + pqd_snappy_decode).
+    Returns the list of decoded byte strings."""
+    blocks = [bytes(b) for b in blocks]
+    src = b"".join(blocks)
+    arr = (N.SnappyBlock * max(len(blocks), 1))()
+    pos = 0
+    for i, b in enumerate(blocks):
+        arr[i].src_off, arr[i].comp_len = pos, len(b)
+        pos += len(b)
+    host = np.frombuffer(src or b"\0", np.uint8)
+    rc = N.decode.pqd_snappy_sizes(host.ctypes.data, len(src), arr, len(blocks))
+    if rc != 0:
+        raise N.PqdError(rc, "bad snappy preamble")
+    total = 0
+    for i in range(len(blocks)):
+        arr[i].dst_off = total
+        total += (arr[i].decoded_len + 16 + 255) // 256 * 256
+    dsrc = N.decode.pqd_device_alloc(ctx.handle, max(len(src), 1))
+    ddst = N.decode.pqd_device_alloc(ctx.handle, max(total, 1))
+    try:
+        if not dsrc or not ddst:
+            raise N.PqdError(-3, "device allocation failed")
+        _check(N.decode.pqd_copy_to_device(ctx.handle, dsrc, host.ctypes.data, max(len(src), 1)), ctx.handle)
+        _check(N.decode.pqd_snappy_decode(ctx.handle, arr, len(blocks), dsrc, len(src), ddst, total), ctx.handle)
+        out = np.zeros(max(total, 1), np.uint8)
+        _check(N.decode.pqd_copy_to_host(ctx.handle, out.ctypes.data, ddst, max(total, 1)), ctx.handle)
+        return [out[arr[i].dst_off:arr[i].dst_off + arr[i].decoded_len].tobytes() for i in range(len(blocks))]
+    finally:
+        if dsrc:
+            N.decode.pqd_device_free(ctx.handle, dsrc)
+        if ddst:
+            N.decode.pqd_device_free(ctx.handle, ddst)
+
+
 def rle_decode(ctx, width, block, max_values, elem_size=1):
     """rle.Read for one level block (int32 length + runs): (values, number of values in the block)."""
     dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[elem_size]

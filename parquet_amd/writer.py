@@ -31,10 +31,13 @@ class Column:
 
 
 class ParquetWriter:
-    def __init__(self, columns, stats=True):
+    def __init__(self, columns, stats=True, codec=0):
+        """codec: 0 UNCOMPRESSED, 1 SNAPPY (every page payload goes through the writer's own snappy compressor)."""
         self.columns = list(columns)
         self._w = N.synth.pqw_create(1 if stats else 0)
         self._open = False
+        if codec:
+            assert N.synth.pqw_set_codec(self._w, codec) == 0
         for c in self.columns:
             t = (C.c_int32 * len(c.types))(*c.types)
             rc = N.synth.pqw_add_column(self._w, c.path.encode(), c.phys_type, c.converted_type, t, len(c.types))
@@ -169,3 +172,14 @@ def write_flat_table(columns, data, rows_per_group, rows_per_page, stats=True):
     out = w.finish()
     w.close()
     return out
+
+
+def snappy_compress(data):
+    """The synthetic writer's snappy compressor on its own (raw block format)."""
+    data = bytes(data)
+    cap = 32 + len(data) + len(data) // 6
+    out = (C.c_uint8 * cap)()
+    src = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+    n = N.synth.pqw_snappy_compress(src, len(data), out, cap)
+    assert n >= 0
+    return bytes(out[:n])

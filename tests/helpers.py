@@ -82,10 +82,10 @@ def random_strings(n, rng, lo=0, hi=24, alphabet=(0, 256)):
 
 
 def build_file(columns, n_rows, rows_per_group, rows_per_page, rng, p_null=0.3, str_len=(0, 24), stats=True,
-               alphabet=(0, 256)):
+               alphabet=(0, 256), codec=0):
     """Random file for arbitrary (nested) columns.  Pages are cut on record boundaries every
     rows_per_page rows, like the reference's chained writers."""
-    w = ParquetWriter(columns, stats=stats)
+    w = ParquetWriter(columns, stats=stats, codec=codec)
     for g0 in range(0, n_rows, rows_per_group):
         g1 = min(n_rows, g0 + rows_per_group)
         w.begin_row_group()

@@ -101,3 +101,50 @@ def test_oracle_reads_the_reference_snappy_fixture_in_place():
             else:
                 assert ch.values.tobytes() == np.ascontiguousarray(e["values"]).tobytes(), (g, name)
         r0 = r1
+
+
+def _snappy_samples():
+    rng = np.random.default_rng(11)
+    words = [b"alpha", b"beta", b"gamma", b"delta", b"", b"x" * 70, b"0123456789abcdef" * 9]
+    return [b"", b"a", b"abc", bytes(100000), bytes(rng.integers(0, 256, 200001, dtype=np.uint8)),
+            b"".join(words[i] for i in rng.integers(0, len(words), 60000)),
+            np.arange(100000, dtype=np.int32).tobytes(), np.repeat(rng.integers(0, 9, 3000), 37).astype(np.int64).tobytes(),
+            bytes(rng.integers(0, 2, 300000, dtype=np.uint8)), b"ab" * 40000 + bytes(rng.integers(0, 256, 70000, dtype=np.uint8))]
+
+
+def test_synthetic_writer_compressor_is_valid_snappy():
+    """The test files' own compressor against the oracle decoder and, where available, C++ snappy."""
+    from parquet_amd.writer import snappy_compress
+    try:
+        import pyarrow as pa
+        codec = pa.Codec("snappy")
+    except Exception:
+        codec = None
+    for data in _snappy_samples():
+        comp = snappy_compress(data)
+        out, err = O.snappy_decode(comp)
+        assert err == 0 and out == data, len(data)
+        if len(data) > 1000 and data != bytes(np.random.default_rng(11).integers(0, 256, 1, dtype=np.uint8)):
+            assert len(comp) <= len(data) + len(data) // 6 + 32
+        if codec is not None and data:
+            assert codec.decompress(comp, decompressed_size=len(data)).to_pybytes() == data
+
+
+def test_oracle_reads_snappy_files_of_the_synthetic_writer():
+    import helpers as H
+    from parquet_amd import _native as N
+    from parquet_amd.writer import Column
+    rng = np.random.default_rng(12)
+    cols = [Column("a", N.INT32, [1]), Column("s", N.BYTE_ARRAY, [1]), Column("b", N.BOOLEAN, [0]),
+            Column("r.x", N.INT64, [2, 1])]
+    state = rng.bit_generator.state
+    plain = H.build_file(cols, 5000, 2500, 700, rng, p_null=0.25, str_len=(0, 12), alphabet=(97, 101))
+    rng.bit_generator.state = state
+    comp = H.build_file(cols, 5000, 2500, 700, rng, p_null=0.25, str_len=(0, 12), alphabet=(97, 101), codec=1)
+    assert len(comp) < len(plain)
+    a, b = H.oracle_file(plain), H.oracle_file(comp)
+    assert a.keys() == b.keys()
+    for k in a:
+        assert a[k].error == 0 and b[k].error == 0
+        assert np.array_equal(a[k].defs, b[k].defs) and np.array_equal(a[k].reps, b[k].reps)
+        assert np.array_equal(a[k].values, b[k].values) and np.array_equal(a[k].sizes, b[k].sizes)
