@@ -45,6 +45,7 @@ constexpr u32 CH_G_LEVELS = 8;    // tiles per hop group (level blocks are ~60 t
 constexpr u32 CH_G_STRINGS = 64;  // tiles per hop group (string pages are thousands of tiles)
 
 constexpr u32 OT = 4096;          // level values per expand tile
+constexpr u32 SN_SPIN_MAX = 1u << 22;  // snappy: polls of a pending copy before it is given up (safety net)
 constexpr u32 SN_T = 65536;       // snappy: output bytes per decode tile (the block size of the usual encoders)
 constexpr u32 EX_CAP = 1024;      // runs staged in LDS per expand batch
 constexpr u32 BT = 4096;          // bools per tile

@@ -1332,10 +1332,11 @@ __global__ void k_str_check(const Region* __restrict__ regions, u32 n_regions, c
 // element records the chain kernels left (out_off, literal position or copy offset).
 //   1. literals: every wave takes 64 elements at a time and copies their literals one after the other
 //      with all lanes (a 64 KiB literal of incompressible data is just a long copy loop);
-//   2. copies, in windows of 256 elements (one per thread): a copy runs as soon as every byte before
-//      its source end is final, i.e. its source ends at or before the output position of the first
-//      unfinished element; the window repeats until all its copies ran.  A copy is a byte loop in LDS,
-//      so a copy that overlaps its own output (offset < length) repeats its pattern as the format says;
+//   2. copies: a bitmap says which output bytes are final; the waves take chunks of 64 elements in
+//      order, one copy per lane, and a copy runs as soon as every byte of its source range is final,
+//      then marks its own bytes.  Chains of copies of copies resolve at LDS latency, without workgroup
+//      barriers.  A copy that overlaps its own output (offset < length) repeats its pattern as the
+//      format says;
 //   3. the tile leaves as aligned 16-byte stores.
 // The usual encoders (golang/snappy, C++ snappy) compress 64 KiB blocks independently, so no copy reaches
 // across a tile boundary; a stream that does is reported as unsupported rather than decoded wrongly.
@@ -1346,8 +1347,8 @@ __global__ __launch_bounds__(256) void k_snappy_tiles(const u8* __restrict__ src
                                                       const u32* __restrict__ otile_first_run,
                                                       const RegionTotal* __restrict__ totals, int* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) u8 s_o[SN_T];
-    __shared__ u32 w_out[257], w_info[256];
-    __shared__ u32 s_flag[4];
+    __shared__ u32 s_fin[SN_T / 32];  // bit i: output byte i of the tile is final
+    __shared__ u32 s_next;
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 ot = blockIdx.x;
     const u32 ri = otile_region[ot];
@@ -1365,69 +1366,163 @@ __global__ __launch_bounds__(256) void k_snappy_tiles(const u8* __restrict__ src
     u32 last = T.cnt;
     if (next_same && nf != ERR_POS && nf + 1 < last) last = nf + 1;
 
-    // ---- 1. literals
+    for (u32 i = tid; i < SN_T / 32; i += 256) s_fin[i] = 0;
+    if (tid == 0) s_next = first;
+    __syncthreads();
+    // sets the bits of tile bytes [a, b), all lanes of a wave together
+    auto mark_wave = [&](u32 a, u32 b) {
+        if (b <= a) return;
+        const u32 w0 = a >> 5, w1 = (b - 1) >> 5;
+        for (u32 w = w0 + lane; w <= w1; w += 64) {
+            u32 m = 0xFFFFFFFFu;
+            if (w == w0) m &= 0xFFFFFFFFu << (a & 31);
+            if (w == w1) m &= 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
+            atomicOr(&s_fin[w], m);
+        }
+    };
+    // ---- 1. literals.  Short ones (the common case) are done lane-parallel, one 16-byte load each, so
+    // that 64 global loads are in flight per wave; long ones are copied by the whole wave in turn.
     for (u32 base = first + wv * 64; base < last; base += 256) {
         const u32 e = base + lane;
-        u32 o = 0, oe = 0, info = 1;
+        u32 lo = 0, hi = 0, sp = 0;
+        bool lit = false;
         if (e < last) {
             const RunRec rr = runs[e];
-            o = rr.out_off; info = rr.info;
-            oe = e + 1 < T.cnt ? runs[e + 1].out_off : n_out;
+            const u32 o = rr.out_off, oe = e + 1 < T.cnt ? runs[e + 1].out_off : n_out;
+            lit = !(rr.info & 1);
+            lo = o > B ? o : B;             // a literal may straddle tiles
+            hi = oe < t_hi ? oe : t_hi;
+            sp = (rr.info >> 1) + (lo - o);
+            if (hi <= lo) lit = false;
         }
-        u64 m = __ballot(e < last && !(info & 1));
+        const bool is_short = lit && hi - lo <= 64;
+        if (is_short) {
+            const u32 n = hi - lo;
+            u32x4 v[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] = 16u * c < n ? load_u128_guarded(rsrc, sp + 16 * c, R.len) : u32x4{0, 0, 0, 0};
+            u8* d = s_o + (lo - B);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const u64 v_lo = v[c].x | ((u64)v[c].y << 32), v_hi = v[c].z | ((u64)v[c].w << 32);
+                for (u32 k = 16 * c; k < n && k < 16u * (c + 1); k++)
+                    d[k] = (u8)((k & 8) ? v_hi >> (8 * (k & 7)) : v_lo >> (8 * (k & 7)));
+            }
+            const u32 a = lo - B, b = hi - B;  // at most 3 bitmap words
+            for (u32 w = a >> 5; w <= (b - 1) >> 5; w++) {
+                u32 m = 0xFFFFFFFFu;
+                if (w == a >> 5) m &= 0xFFFFFFFFu << (a & 31);
+                if (w == (b - 1) >> 5) m &= 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
+                atomicOr(&s_fin[w], m);
+            }
+        }
+        u64 m = __ballot(lit && !is_short);
         while (m) {
             const int l = __ffsll((unsigned long long)m) - 1;
             m &= m - 1;
-            const u32 lo_ = __shfl(o, l), hi_ = __shfl(oe, l), sp = __shfl(info, l) >> 1;
-            const u32 lo = lo_ > B ? lo_ : B, hi = hi_ < t_hi ? hi_ : t_hi;  // a literal may straddle tiles
-            if (hi > lo) {
-                const u8* s = rsrc + sp + (lo - lo_);
-                u8* d = s_o + (lo - B);
-                for (u32 k = lane; k < hi - lo; k += 64) d[k] = s[k];
+            const u32 lo_ = __shfl(lo, l), hi_ = __shfl(hi, l), sp_ = __shfl(sp, l);
+            u8* d = s_o + (lo_ - B);
+            const u32 n = hi_ - lo_;
+            const bool aligned = ((lo_ - B) & 3) == 0;
+            for (u32 k = lane * 16; k < n; k += 64 * 16) {  // 1 KiB per wave step
+                const u32x4 v = load_u128_guarded(rsrc, sp_ + k, R.len);
+                if (aligned && k + 16 <= n) {
+                    u32* dw = (u32*)(d + k);
+                    dw[0] = v.x; dw[1] = v.y; dw[2] = v.z; dw[3] = v.w;
+                } else {
+                    const u64 v_lo = v.x | ((u64)v.y << 32), v_hi = v.z | ((u64)v.w << 32);
+                    for (u32 j = 0; j < 16 && k + j < n; j++) d[k + j] = (u8)(j < 8 ? v_lo >> (8 * j) : v_hi >> (8 * (j - 8)));
+                }
             }
+            mark_wave(lo_ - B, hi_ - B);
         }
     }
     __syncthreads();
 
-    // ---- 2. copies, window by window
-    for (u32 w0 = first; w0 < last; w0 += 256) {
-        const u32 e = w0 + tid;
-        const u32 wn = last - w0 < 256 ? last - w0 : 256;
-        if (tid < wn) {
-            const RunRec rr = runs[e];
-            w_out[tid] = rr.out_off;
-            w_info[tid] = rr.info;
+    // ---- 2. copies.  Every wave takes the next 64 elements (in order) and loops on its own until all its
+    // copies ran; a copy whose source bytes come from another wave's elements simply stays pending until
+    // their bits appear.  No workgroup barrier: the earliest unfinished chunk can always progress, because
+    // everything before it is final or in the hands of a wave that is running.
+    volatile u32* fin = s_fin;
+    auto mark_range = [&](u32 a, u32 b) {  // a thread's own bytes: at most 64, so at most 3 words
+        for (u32 w = a >> 5; w <= (b - 1) >> 5; w++) {
+            u32 m = 0xFFFFFFFFu;
+            if (w == a >> 5) m &= 0xFFFFFFFFu << (a & 31);
+            if (w == (b - 1) >> 5) m &= 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
+            atomicOr(&s_fin[w], m);
         }
-        if (tid == 0) w_out[wn] = w0 + wn < T.cnt ? runs[w0 + wn].out_off : n_out;
-        __syncthreads();
+    };
+    for (;;) {
+        u32 w0 = 0;
+        if (lane == 0) w0 = atomicAdd(&s_next, 64u);
+        w0 = __shfl(w0, 0);
+        if (w0 >= last) break;
+        const u32 e = w0 + lane;
         bool pending = false;
         u32 o = 0, len = 0, off = 0;
-        if (tid < wn && (w_info[tid] & 1)) {
-            o = w_out[tid];
-            len = w_out[tid + 1] - o;
-            off = w_info[tid] >> 1;
-            pending = true;
-            if (off > o) { set_status(status, ST_CORRUPT, ri); pending = false; }               // d < offset
-            else if (o < B || o + len > t_hi || o - off < B) { set_status(status, ST_UNSUPPORTED, ri); pending = false; }
+        if (e < last) {
+            const RunRec rr = runs[e];
+            if (rr.info & 1) {
+                o = rr.out_off;
+                len = (e + 1 < T.cnt ? runs[e + 1].out_off : n_out) - o;
+                off = rr.info >> 1;
+                pending = true;
+                int bad = 0;
+                if (off > o) bad = ST_CORRUPT;                                          // d < offset
+                else if (o < B || o + len > t_hi || o - off < B) bad = ST_UNSUPPORTED;  // reaches across tiles
+                if (bad) {
+                    // its bytes count as final all the same, so that nothing waits for them forever
+                    set_status(status, bad, ri);
+                    const u32 a = (o > B ? o : B), b = (o + len < t_hi ? o + len : t_hi);
+                    if (b > a) mark_range(a - B, b - B);
+                    pending = false;
+                }
+            }
         }
-        const u32 src_end = o - off + (len < off ? len : off);
-        for (;;) {
-            // W = output position of the first element of the window that has not run yet
-            const u64 pm = __ballot(pending);
-            if (lane == 0) s_flag[wv] = pm ? (u32)(wv * 64 + __ffsll((unsigned long long)pm) - 1) : 0xFFFFFFFFu;
-            __syncthreads();
-            u32 fp = s_flag[0];
-            fp = s_flag[1] < fp ? s_flag[1] : fp;
-            fp = s_flag[2] < fp ? s_flag[2] : fp;
-            fp = s_flag[3] < fp ? s_flag[3] : fp;
-            if (fp == 0xFFFFFFFFu) break;
-            const u32 W = w_out[fp];
-            if (pending && src_end <= W) {
-                u8* d = s_o + (o - B);
-                for (u32 k = 0; k < len; k++) d[k] = d[(int)k - (int)off];
+        // source bytes [sa, sb) and own bytes [da, db), tile relative
+        const u32 da = o - B, db = da + len, sa = da - off, sb = sa + (len < off ? len : off);
+        u32 spins = 0;
+        while (__any(pending)) {
+            bool ready = false;
+            if (pending) {
+                ready = true;
+                for (u32 w = sa >> 5; w <= (sb - 1) >> 5; w++) {
+                    u32 m = 0xFFFFFFFFu;
+                    if (w == sa >> 5) m &= 0xFFFFFFFFu << (sa & 31);
+                    if (w == (sb - 1) >> 5) m &= 0xFFFFFFFFu >> (31 - ((sb - 1) & 31));
+                    ready = ready && (fin[w] & m) == m;
+                }
+            }
+            if (ready) {
+                __threadfence_block();  // the bits were set after the bytes they stand for
+                // d[k] = d[k - off], byte by byte in the format's terms.  A byte loop in LDS costs a full LDS
+                // round trip per byte, so bytes move 8 at a time (8 reads in flight, then 8 writes).  That needs
+                // a distance of at least 8: an overlapping copy with a shorter offset repeats a pattern of `off`
+                // bytes, and any multiple of `off` is an equally good distance once that many bytes exist.
+                u8* d = s_o + da;
+                u32 o2 = off, k = 0;
+                if (off < 8) {
+                    o2 = off * ((7 + off) / off);
+                    const u32 head = len < o2 - off ? len : o2 - off;
+                    for (; k < head; k++) d[k] = d[(int)k - (int)off];
+                }
+                for (; k + 8 <= len; k += 8) {
+                    u8 t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) t[j] = d[(int)(k + j) - (int)o2];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) d[k + j] = t[j];
+                }
+                for (; k < len; k++) d[k] = d[(int)k - (int)o2];
+                __threadfence_block();  // bytes before bits
+                mark_range(da, db);
+                pending = false;
+            } else if (pending && ++spins > SN_SPIN_MAX) {
+                // cannot happen while every element marks its bytes; never spin forever on a GPU
+                set_status(status, ST_CORRUPT, ri);
+                mark_range(da, db);
                 pending = false;
             }
-            __syncthreads();
         }
     }
     __syncthreads();
