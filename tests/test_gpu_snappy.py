@@ -115,3 +115,41 @@ def test_reader_api_on_a_snappy_file(ctx):
         assert rd.scan() is not None
         n += 1
     assert rd.error() is None and n == 3000 == rd.rows()
+
+
+def _uvarint(v):
+    out = []
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def test_bad_copy_with_dependents_is_an_error_not_a_hang(ctx):
+    """A copy that reaches before the start of the output, followed by copies of its bytes."""
+    body = b"\x0cabcd" + bytes([(3 << 2) | 2, 5, 0])   # literal 'abcd', copy2 length 4 offset 5: d < offset
+    n = 8
+    for _ in range(300):
+        body += bytes([(3 << 2) | 2, 4, 0])           # each copies the 4 bytes before it
+        n += 4
+    block = _uvarint(n) + body
+    assert O.snappy_decode(block)[0] is None
+    with pytest.raises(N.PqdError) as e:
+        R.snappy_decode_blocks(ctx, [block])
+    assert e.value.code == N.E_CORRUPT
+
+
+def test_copy_across_64k_output_blocks_is_reported_unsupported(ctx):
+    """Valid snappy that no block-wise encoder writes: a copy whose source lies in the previous 64 KiB of
+    output.  The oracle (like snappy.Decode) reads it; the device decoder says so instead of guessing."""
+    rng = np.random.default_rng(3)
+    a = bytes(rng.integers(0, 256, 65530, dtype=np.uint8))
+    b = bytes(rng.integers(0, 256, 10, dtype=np.uint8))
+    lit = lambda x: (bytes([61 << 2]) + (len(x) - 1).to_bytes(2, "little") if len(x) > 60 else bytes([(len(x) - 1) << 2])) + x
+    block = _uvarint(65530 + 10 + 8) + lit(a) + lit(b) + bytes([(7 << 2) | 2, 12, 0])
+    want, err = O.snappy_decode(block)
+    assert err == 0 and want == a + b + (a + b)[-12:-4]
+    with pytest.raises(N.PqdError) as e:
+        R.snappy_decode_blocks(ctx, [block])
+    assert e.value.code == N.E_UNSUPPORTED
