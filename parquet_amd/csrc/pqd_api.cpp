@@ -53,7 +53,7 @@ struct pqd_plan {
     std::vector<PageRec> pages;
     std::vector<Region> lregions, sregions;
     std::vector<u32> otile_region;
-    std::vector<u32> ltile_prefix, lotile_prefix, stile_chain_prefix, lgroup_prefix, sgroup_prefix;
+    std::vector<u32> ltile_prefix, lotile_prefix, stile_chain_prefix, lgroup_prefix, sgroup_prefix, ssuper_prefix;
     std::vector<Seg> segs;
     std::vector<u32> seg_blk_prefix;
     std::vector<u32> bool_pages, btile_prefix, row_chunks, rtile_prefix;
@@ -67,7 +67,7 @@ struct pqd_plan {
     Region *d_lregions = nullptr, *d_sregions = nullptr;
     u32* d_otile_region = nullptr;
     u32 *d_ltile_prefix = nullptr, *d_lotile_prefix = nullptr, *d_stile_chain_prefix = nullptr;
-    u32 *d_lgroup_prefix = nullptr, *d_sgroup_prefix = nullptr;
+    u32 *d_lgroup_prefix = nullptr, *d_sgroup_prefix = nullptr, *d_ssuper_prefix = nullptr;
     Seg* d_segs = nullptr; u32* d_seg_blk_prefix = nullptr;
     u32 *d_bool_pages = nullptr, *d_btile_prefix = nullptr;
     u32 *d_row_chunks = nullptr, *d_rtile_prefix = nullptr;
@@ -331,6 +331,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->stile_chain_prefix.push_back(0);
     pl->lgroup_prefix.push_back(0);
     pl->sgroup_prefix.push_back(0);
+    pl->ssuper_prefix.push_back(0);
     pl->btile_prefix.push_back(0);
     pl->rtile_prefix.push_back(0);
     pl->seg_blk_prefix.push_back(0);
@@ -382,6 +383,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                 pl->sregions.push_back(R);
                 push_prefix(pl->stile_chain_prefix, ((u64)P.val_len + CH_T - 1) / CH_T, ovf);
                 push_prefix(pl->sgroup_prefix, ((u64)P.val_len + CH_G_STRINGS * CH_T - 1) / (CH_G_STRINGS * CH_T), ovf);
+                push_prefix(pl->ssuper_prefix, ((u64)P.val_len + (u64)CH_SUPER * CH_G_STRINGS * CH_T - 1) / ((u64)CH_SUPER * CH_G_STRINGS * CH_T), ovf);
             } else if (C.phys_type == PQD_BOOLEAN) {
                 pl->bool_pages.push_back(pi);
                 push_prefix(pl->btile_prefix, ((u64)P.num_values + BT - 1) / BT, ovf);
@@ -414,6 +416,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_sctp = ap.take(pl->stile_chain_prefix.size() * 4);
     const size_t o_lgp = ap.take(pl->lgroup_prefix.size() * 4);
     const size_t o_sgp = ap.take(pl->sgroup_prefix.size() * 4);
+    const size_t o_ssp = ap.take(pl->ssuper_prefix.size() * 4);
     const size_t o_bp = ap.take(pl->bool_pages.size() * 4);
     const size_t o_btp = ap.take(pl->btile_prefix.size() * 4);
     const size_t o_rc = ap.take(pl->row_chunks.size() * 4);
@@ -425,6 +428,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const u32 n_lgroups = pl->lgroup_prefix.back(), n_sgroups = pl->sgroup_prefix.back();
     const size_t o_lgexit = ap.take((size_t)n_lgroups * CH_E_LEVELS * sizeof(ExitRec));
     const size_t o_sgexit = ap.take((size_t)n_sgroups * CH_E_STRINGS * sizeof(ExitRec));
+    const u32 n_ssupers = pl->ssuper_prefix.back();
+    const size_t o_ssexit = ap.take((size_t)n_ssupers * CH_E_STRINGS * sizeof(ExitRec));
     const size_t o_ltot = ap.take(pl->lregions.size() * sizeof(RegionTotal));
     const size_t o_stot = ap.take(pl->sregions.size() * sizeof(RegionTotal));
     const size_t o_runs = ap.take((size_t)run_base * sizeof(RunRec));
@@ -437,6 +442,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_ste = ap.take((size_t)pl->n_stiles_chain * sizeof(TileEntry));
     const size_t o_lge = ap.take((size_t)n_lgroups * sizeof(TileEntry));
     const size_t o_sge = ap.take((size_t)n_sgroups * sizeof(TileEntry));
+    const size_t o_sse = ap.take((size_t)n_ssupers * sizeof(TileEntry));
     const size_t o_otf = ap.take(((size_t)pl->n_lotiles + 1) * 4);  // one spare entry
     const size_t ff_end = ap.total;
     // reset to 0 every run
@@ -505,6 +511,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->d_ltile_prefix = (u32*)(A + o_ltp); pl->d_lotile_prefix = (u32*)(A + o_lotp);
     pl->d_stile_chain_prefix = (u32*)(A + o_sctp);
     pl->d_lgroup_prefix = (u32*)(A + o_lgp); pl->d_sgroup_prefix = (u32*)(A + o_sgp);
+    pl->d_ssuper_prefix = (u32*)(A + o_ssp);
     pl->d_lgexit = (ExitRec*)(A + o_lgexit); pl->d_sgexit = (ExitRec*)(A + o_sgexit);
     pl->d_lgroup_entry = (TileEntry*)(A + o_lge); pl->d_sgroup_entry = (TileEntry*)(A + o_sge);
     pl->d_bool_pages = (u32*)(A + o_bp); pl->d_btile_prefix = (u32*)(A + o_btp);
@@ -525,7 +532,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->lchain = ChainArgs{pl->d_lregions, pl->d_ltile_prefix, pl->d_lgroup_prefix, (u32)pl->lregions.size(), pl->n_ltiles, n_lgroups,
                            pl->d_lexit, pl->d_lgexit, pl->d_ltile_entry, pl->d_lgroup_entry, pl->d_ltotals};
     pl->schain = ChainArgs{pl->d_sregions, pl->d_stile_chain_prefix, pl->d_sgroup_prefix, (u32)pl->sregions.size(), pl->n_stiles_chain,
-                           n_sgroups, pl->d_sexit, pl->d_sgexit, pl->d_stile_entry, pl->d_sgroup_entry, pl->d_stotals, A + o_scp};
+                           n_sgroups, pl->d_sexit, pl->d_sgexit, pl->d_stile_entry, pl->d_sgroup_entry, pl->d_stotals, A + o_scp,
+                           (u32*)(A + o_ssp), n_ssupers, (ExitRec*)(A + o_ssexit), (TileEntry*)(A + o_sse)};
 
     int rc;
     if ((rc = upload(ctx, pl->d_chunks, pl->chunks))) return rc;
@@ -538,6 +546,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if ((rc = upload(ctx, pl->d_stile_chain_prefix, pl->stile_chain_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_lgroup_prefix, pl->lgroup_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_sgroup_prefix, pl->sgroup_prefix))) return rc;
+    if ((rc = upload(ctx, pl->d_ssuper_prefix, pl->ssuper_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_bool_pages, pl->bool_pages))) return rc;
     if ((rc = upload(ctx, pl->d_btile_prefix, pl->btile_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_row_chunks, pl->row_chunks))) return rc;
@@ -910,7 +919,7 @@ int pqd_snappy_decode(pqd_ctx* ctx, const pqd_snappy_block* blocks, size_t n, co
         R.out = (u8*)dst_device + b.dst_off;
         R.page = (u32)i;
         R.count_level = ERR_POS;
-        const u64 nt = ((u64)R.len + CH_T - 1) / CH_T, ng = ((u64)R.len + (u64)CH_G_STRINGS * CH_T - 1) / ((u64)CH_G_STRINGS * CH_T);
+        const u64 nt = ((u64)R.len + CH_T - 1) / CH_T, ng = ((u64)R.len + (u64)CH_G_SNAPPY * CH_T - 1) / ((u64)CH_G_SNAPPY * CH_T);
         const u64 no = ((u64)b.decoded_len + SN_T - 1) / SN_T;
         if ((u64)tile_prefix.back() + nt > 0x7fffffffull || n_otiles + no > 0x7fffffffull)
             return fail(ctx, PQD_E_UNSUPPORTED, "batch too large for 32-bit tile indices");

@@ -42,7 +42,10 @@ constexpr u32 CH_E_STRINGS = 64;  // covers values up to 60 bytes; longer ones t
 
 constexpr u32 CH_SERIAL = 64;     // level tiles with at most this many runs are marked by a serial walk
 constexpr u32 CH_G_LEVELS = 8;    // tiles per hop group (level blocks are ~60 tiles per 1M-value page)
-constexpr u32 CH_G_STRINGS = 64;  // tiles per hop group (string pages are thousands of tiles)
+constexpr u32 CH_G_STRINGS = 16;  // tiles per hop group (string pages are thousands of tiles: they get a super level)
+constexpr u32 CH_G_SNAPPY = 64;   // tiles per hop group of a snappy block
+constexpr u32 CH_SUPER = 16;      // groups per super-group (strings only)
+constexpr u32 chain_group_tiles(int kind) { return kind == KIND_LEVELS ? CH_G_LEVELS : kind == KIND_STRINGS ? CH_G_STRINGS : CH_G_SNAPPY; }
 
 constexpr u32 OT = 4096;          // level values per expand tile
 constexpr u32 SN_SPIN_MAX = 1u << 22;  // snappy: polls of a pending copy before it is given up (safety net)
@@ -114,6 +117,10 @@ struct ChainArgs {
     TileEntry* group_entry;   // n_groups  (reset to 0xFF before every run)
     RegionTotal* totals;      // n_regions
     void* str_cp;             // strings: n_tiles * 64 rows of 8 u16 walk checkpoints (1 KiB per tile)
+    const u32* super_prefix;  // n_regions + 1; super-groups are optional (n_supers == 0: three levels)
+    u32 n_supers;
+    ExitRec* sexit;           // n_supers * E
+    TileEntry* super_entry;   // n_supers  (reset to 0xFF before every run)
 };
 hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs& a, RunRec* run_tbl, u32* otile_first_run,
                         const PageDyn* page_dyn, int* status, int phase);

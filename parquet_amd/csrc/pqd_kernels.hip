@@ -757,12 +757,32 @@ static __device__ __forceinline__ u32 hop_tile(const Region& R, const GlobalByte
     return q;
 }
 
+// One hop over a group: the chain is at region position p; returns where it leaves p's group, through
+// the group exit table when the entry is tabulated there, tile by tile otherwise.
+template <int KIND>
+static __device__ __forceinline__ u32 hop_group(const Region& R, const GlobalBytes& B, const ExitRec* __restrict__ exit_tbl,
+                                                const ExitRec* __restrict__ gexit, u32 p, u32& cnt, u64& vals) {
+    constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
+    constexpr u32 G = chain_group_tiles(KIND);
+    const u32 L = R.len, g = p / (G * CH_T), off = p - g * G * CH_T;
+    ExitRec x;
+    x.tgt = UNKNOWN_POS;
+    if (off < E) x = gexit[(u64)(R.group_base + g) * E + off];
+    if (x.tgt != UNKNOWN_POS) {
+        cnt += x.cnt; vals += x.vals;
+        return x.tgt;
+    }
+    const u32 g_hi = (g + 1) * G * CH_T < L ? (g + 1) * G * CH_T : L;
+    while (p < g_hi) p = hop_tile<KIND>(R, B, exit_tbl, p, cnt, vals);
+    return p;
+}
+
 template <int KIND>
 __global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                      const u32* __restrict__ group_prefix, u32 n_regions,
                                                      const ExitRec* __restrict__ exit_tbl, ExitRec* __restrict__ gexit) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
-    constexpr u32 G = KIND == KIND_LEVELS ? CH_G_LEVELS : CH_G_STRINGS;
+    constexpr u32 G = chain_group_tiles(KIND);
     const u32 group = blockIdx.x / (E / 64);
     const u32 i = (blockIdx.x % (E / 64)) * 64 + threadIdx.x;  // entry offset into the group's first tile
     const u32 ri = find_owner(group_prefix, n_regions, group);
@@ -786,13 +806,51 @@ __global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_
     gexit[(u64)group * E + i] = x;
 }
 
+// Super-groups (CH_SUPER groups each) add a fourth level for regions of thousands of tiles (string pages):
+//   k_chain_supers        like k_chain_groups one level up: per super-group and tabulated entry, where the
+//                         chain leaves the super-group (hops through the group exit table)
+//   k_chain_resolve       then walks super-groups and records their entries
+//   k_chain_super_groups  one thread per super-group walks its groups and records the group entries
+template <int KIND>
+__global__ __launch_bounds__(64) void k_chain_supers(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                                                     const u32* __restrict__ super_prefix, u32 n_regions,
+                                                     const ExitRec* __restrict__ gexit, ExitRec* __restrict__ sexit) {
+    constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
+    constexpr u32 GB = chain_group_tiles(KIND) * CH_T;  // bytes per group
+    const u32 sup = blockIdx.x / (E / 64);
+    const u32 i = (blockIdx.x % (E / 64)) * 64 + threadIdx.x;
+    const u32 ri = find_owner(super_prefix, n_regions, sup);
+    const Region R = regions[ri];
+    const u32 L = R.len;
+    const u64 s_lo64 = (u64)(sup - super_prefix[ri]) * CH_SUPER * GB;
+    const u32 s_lo = (u32)s_lo64;
+    const u32 s_hi = s_lo64 + (u64)CH_SUPER * GB < L ? (u32)(s_lo64 + (u64)CH_SUPER * GB) : L;
+    u32 p = s_lo + i, cnt = 0;
+    u64 vals = 0;
+    if (p >= s_hi) return;
+    while (p < s_hi) {
+        const u32 g = p / GB, off = p - g * GB;
+        ExitRec x;
+        x.tgt = UNKNOWN_POS;
+        if (off < E) x = gexit[(u64)(R.group_base + g) * E + off];
+        if (x.tgt == UNKNOWN_POS) { p = UNKNOWN_POS; break; }  // not tabulated: the true chain is walked later
+        cnt += x.cnt; vals += x.vals;
+        p = x.tgt;
+    }
+    ExitRec x;
+    x.tgt = p; x.cnt = cnt; x.vals = vals;
+    sexit[(u64)sup * E + i] = x;
+}
+
 template <int KIND>
 __global__ void k_chain_resolve(const u8* __restrict__ src_base, const Region* __restrict__ regions, u32 n_regions,
                                 const ExitRec* __restrict__ exit_tbl, const ExitRec* __restrict__ gexit,
+                                const u32* __restrict__ super_prefix, const ExitRec* __restrict__ sexit,
+                                TileEntry* __restrict__ super_entry,
                                 TileEntry* __restrict__ group_entry, RegionTotal* __restrict__ totals,
                                 int* __restrict__ status) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
-    constexpr u32 G = KIND == KIND_LEVELS ? CH_G_LEVELS : CH_G_STRINGS;
+    constexpr u32 G = chain_group_tiles(KIND);
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_regions) return;
     const Region R = regions[r];
@@ -800,20 +858,32 @@ __global__ void k_chain_resolve(const u8* __restrict__ src_base, const Region* _
     const GlobalBytes B{src_base + R.src_off};
     u32 p = 0, cnt = 0;
     u64 vals = 0;
-    while (p < L) {
-        const u32 g = p / (G * CH_T), off = p - g * G * CH_T;
-        TileEntry ge;
-        ge.pos = p; ge.cnt = cnt; ge.vals = vals;
-        group_entry[R.group_base + g] = ge;
-        ExitRec x;
-        x.tgt = UNKNOWN_POS;
-        if (off < E) x = gexit[(u64)(R.group_base + g) * E + off];
-        if (x.tgt != UNKNOWN_POS) {
-            cnt += x.cnt; vals += x.vals;
-            p = x.tgt;
-        } else {
-            const u32 g_hi = (g + 1) * G * CH_T < L ? (g + 1) * G * CH_T : L;
-            while (p < g_hi) p = hop_tile<KIND>(R, B, exit_tbl, p, cnt, vals);
+    if (sexit) {
+        const u64 SB = (u64)CH_SUPER * G * CH_T;  // bytes per super-group
+        while (p < L) {
+            const u32 sg = (u32)(p / SB);
+            const u64 off = p - sg * SB;
+            TileEntry se;
+            se.pos = p; se.cnt = cnt; se.vals = vals; se.n = 0; se.pad = 0;
+            super_entry[super_prefix[r] + sg] = se;
+            ExitRec x;
+            x.tgt = UNKNOWN_POS;
+            if (off < E) x = sexit[(u64)(super_prefix[r] + sg) * E + off];
+            if (x.tgt != UNKNOWN_POS) {
+                cnt += x.cnt; vals += x.vals;
+                p = x.tgt;
+            } else {
+                const u64 s_hi64 = (sg + 1) * SB;
+                const u32 s_hi = s_hi64 < L ? (u32)s_hi64 : L;
+                while (p < s_hi) p = hop_group<KIND>(R, B, exit_tbl, gexit, p, cnt, vals);
+            }
+        }
+    } else {
+        while (p < L) {
+            TileEntry ge;
+            ge.pos = p; ge.cnt = cnt; ge.vals = vals; ge.n = 0; ge.pad = 0;
+            group_entry[R.group_base + p / (G * CH_T)] = ge;
+            p = hop_group<KIND>(R, B, exit_tbl, gexit, p, cnt, vals);
         }
     }
     const bool err = p == ERR_POS;
@@ -826,11 +896,38 @@ __global__ void k_chain_resolve(const u8* __restrict__ src_base, const Region* _
 }
 
 template <int KIND>
+__global__ void k_chain_super_groups(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                                     const u32* __restrict__ super_prefix, u32 n_regions, u32 n_supers,
+                                     const ExitRec* __restrict__ exit_tbl, const ExitRec* __restrict__ gexit,
+                                     const TileEntry* __restrict__ super_entry, TileEntry* __restrict__ group_entry) {
+    constexpr u32 G = chain_group_tiles(KIND);
+    const u32 sup = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sup >= n_supers) return;
+    const TileEntry se = super_entry[sup];
+    if (se.pos == ERR_POS) return;  // the true chain never starts an element in this super-group
+    const u32 ri = find_owner(super_prefix, n_regions, sup);
+    const Region R = regions[ri];
+    const u32 L = R.len;
+    const u64 SB = (u64)CH_SUPER * G * CH_T;
+    const u64 s_hi64 = (u64)(sup - super_prefix[ri] + 1) * SB;
+    const u32 s_hi = s_hi64 < L ? (u32)s_hi64 : L;
+    const GlobalBytes B{src_base + R.src_off};
+    u32 p = se.pos, cnt = se.cnt;
+    u64 vals = se.vals;
+    while (p < s_hi) {
+        TileEntry ge;
+        ge.pos = p; ge.cnt = cnt; ge.vals = vals; ge.n = 0; ge.pad = 0;
+        group_entry[R.group_base + p / (G * CH_T)] = ge;
+        p = hop_group<KIND>(R, B, exit_tbl, gexit, p, cnt, vals);
+    }
+}
+
+template <int KIND>
 __global__ void k_chain_tiles(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                               const u32* __restrict__ group_prefix, u32 n_regions, u32 n_groups,
                               const ExitRec* __restrict__ exit_tbl, const TileEntry* __restrict__ group_entry,
                               TileEntry* __restrict__ tile_entry) {
-    constexpr u32 G = KIND == KIND_LEVELS ? CH_G_LEVELS : CH_G_STRINGS;
+    constexpr u32 G = chain_group_tiles(KIND);
     const u32 group = blockIdx.x * blockDim.x + threadIdx.x;
     if (group >= n_groups) return;
     const TileEntry ge = group_entry[group];
@@ -1721,10 +1818,22 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
                                a.group_prefix, a.n_regions, a.exit_tbl, a.gexit);
             LAUNCH_CHECK();
         }
+        const bool supers = a.n_supers > 0;
+        if (supers) {
+            hipLaunchKernelGGL((k_chain_supers<KIND>), dim3(a.n_supers * (E / 64)), dim3(64), 0, st, src, a.regions,
+                               a.super_prefix, a.n_regions, a.gexit, a.sexit);
+            LAUNCH_CHECK();
+        }
         // the region hop also runs for empty regions: it writes their (zero) totals
         hipLaunchKernelGGL((k_chain_resolve<KIND>), dim3((a.n_regions + 63) / 64), dim3(64), 0, st, src, a.regions, a.n_regions,
-                           a.exit_tbl, a.gexit, a.group_entry, a.totals, status);
+                           a.exit_tbl, a.gexit, a.super_prefix, supers ? a.sexit : nullptr, a.super_entry, a.group_entry,
+                           a.totals, status);
         LAUNCH_CHECK();
+        if (supers) {
+            hipLaunchKernelGGL((k_chain_super_groups<KIND>), dim3((a.n_supers + 63) / 64), dim3(64), 0, st, src, a.regions,
+                               a.super_prefix, a.n_regions, a.n_supers, a.exit_tbl, a.gexit, a.super_entry, a.group_entry);
+            LAUNCH_CHECK();
+        }
         if (a.n_tiles) {
             hipLaunchKernelGGL((k_chain_tiles<KIND>), dim3((a.n_groups + 63) / 64), dim3(64), 0, st, src, a.regions,
                                a.group_prefix, a.n_regions, a.n_groups, a.exit_tbl, a.group_entry, a.tile_entry);
