@@ -19,6 +19,7 @@ struct pqd_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream of the PLAIN value gather
     bool overlap = true;            // PQD_OVERLAP=0 keeps everything on one stream
+    bool graph = false;             // PQD_GRAPH=1 replays chain batches as a captured HIP graph
     std::string err;
     u32 copy_grid = 0x7fffffffu;  // one block per 4 KiB tile; PQD_COPY_GRID caps it (then blocks grid-stride)
 };
@@ -88,6 +89,9 @@ struct pqd_plan {
     static constexpr int EV_RING = 256;
     hipEvent_t ev[EV_RING][4] = {};
     hipEvent_t ev_fork = nullptr;  // orders the value gather's side stream after the run start
+    hipEvent_t ev_join = nullptr;  // ... and the run's end after the gather (graph capture)
+    hipGraphExec_t gexec = nullptr;  // captured run (see pqd_plan_run)
+    const u8* gsrc = nullptr;        // the source pointer the graph was captured with
     uint64_t runs = 0;
     bool ran = false, synced = false;
     int last_status = 0;
@@ -140,6 +144,8 @@ int pqd_create(int device, pqd_ctx** out) {
     if (g && atoi(g) > 0) ctx->copy_grid = (u32)atoi(g);
     const char* ov = getenv("PQD_OVERLAP");
     if (ov) ctx->overlap = atoi(ov) != 0;
+    const char* gr = getenv("PQD_GRAPH");
+    if (gr) ctx->graph = atoi(gr) != 0;
     *out = ctx;
     return PQD_OK;
 }
@@ -198,6 +204,8 @@ void pqd_plan_destroy(pqd_plan* pl) {
         for (hipEvent_t e : set)
             if (e) (void)hipEventDestroy(e);
     if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
+    if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
+    if (pl->gexec) (void)hipGraphExecDestroy(pl->gexec);
     delete pl;
 }
 
@@ -557,24 +565,20 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     for (auto& set : pl->ev)
         for (hipEvent_t& e : set) HIP_TRY(ctx, hipEventCreate(&e));
     HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
     pl->h_chunk_dyn.resize(n_chunks);
     guard.p = nullptr;
     *out = pl;
     return PQD_OK;
 }
 
-int pqd_plan_run(pqd_plan* pl, const void* src_device) {
-    if (!pl || !src_device) return PQD_E_ARG;
+// Queues one run of the plan on the decoder's streams.  ev_c0 / ev_c1 bracket the PLAIN value gather when
+// given; under graph capture they are absent and a plain join event orders the two streams.
+static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t ev_c1) {
     pqd_ctx* ctx = pl->ctx;
     hipStream_t st = ctx->stream;
-    const u8* src = (const u8*)src_device;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     const u32 n_chunks = (u32)pl->chunks.size(), n_pages = (u32)pl->pages.size();
     const u32 n_lreg = (u32)pl->lregions.size(), n_sreg = (u32)pl->sregions.size();
-    pl->last_src = src;
-    pl->synced = false;
-    hipEvent_t* ev = pl->ev[pl->runs % pqd_plan::EV_RING];
-    HIP_TRY(ctx, hipEventRecord(ev[0], st));
     if (pl->n_ltiles + pl->n_stiles_chain + pl->n_lotiles)
         HIP_TRY(ctx, hipMemsetAsync(pl->ff_begin, 0xFF, pl->ff_bytes, st));
     HIP_TRY(ctx, hipMemsetAsync(pl->zero_begin, 0, pl->zero_bytes, st));
@@ -588,9 +592,10 @@ int pqd_plan_run(pqd_plan* pl, const void* src_device) {
         HIP_TRY(ctx, hipEventRecord(pl->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(cst, pl->ev_fork, 0));
     }
-    HIP_TRY(ctx, hipEventRecord(ev[2], cst));
+    if (ev_c0) HIP_TRY(ctx, hipEventRecord(ev_c0, cst));
     HIP_TRY(ctx, launch_copy(cst, src, pl->d_segs, pl->d_seg_blk_prefix, (u32)pl->segs.size(), pl->n_copy_blocks, ctx->copy_grid));
-    HIP_TRY(ctx, hipEventRecord(ev[3], cst));
+    if (ev_c1) HIP_TRY(ctx, hipEventRecord(ev_c1, cst));
+    else if (side) HIP_TRY(ctx, hipEventRecord(pl->ev_join, cst));
 
     // levels
     if (n_lreg) {
@@ -609,7 +614,44 @@ int pqd_plan_run(pqd_plan* pl, const void* src_device) {
     }
     HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
                              pl->d_row_tiles, pl->d_chunk_dyn));
-    if (side) HIP_TRY(ctx, hipStreamWaitEvent(st, ev[3], 0));
+    if (side) HIP_TRY(ctx, hipStreamWaitEvent(st, ev_c1 ? ev_c1 : pl->ev_join, 0));
+    return PQD_OK;
+}
+
+int pqd_plan_run(pqd_plan* pl, const void* src_device) {
+    if (!pl || !src_device) return PQD_E_ARG;
+    pqd_ctx* ctx = pl->ctx;
+    hipStream_t st = ctx->stream;
+    const u8* src = (const u8*)src_device;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pl->last_src = src;
+    pl->synced = false;
+    hipEvent_t* ev = pl->ev[pl->runs % pqd_plan::EV_RING];
+    HIP_TRY(ctx, hipEventRecord(ev[0], st));
+    // Batches with level or string chains are a dozen or more short launches: those are captured once into a
+    // HIP graph and replayed (no per-gather timing in that mode).  A pure PLAIN batch is one long kernel.
+    const bool use_graph = ctx->graph && (!pl->lregions.empty() || !pl->sregions.empty());
+    if (use_graph) {
+        if (!pl->gexec || pl->gsrc != src) {
+            if (pl->gexec) { (void)hipGraphExecDestroy(pl->gexec); pl->gexec = nullptr; }
+            HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_run(pl, src, nullptr, nullptr);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) return fail(ctx, PQD_E_HIP, "hipStreamEndCapture", e);
+            const hipError_t e2 = hipGraphInstantiate(&pl->gexec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e2 != hipSuccess) { pl->gexec = nullptr; return fail(ctx, PQD_E_HIP, "hipGraphInstantiate", e2); }
+            pl->gsrc = src;
+        }
+        HIP_TRY(ctx, hipEventRecord(ev[2], st));
+        HIP_TRY(ctx, hipEventRecord(ev[3], st));
+        HIP_TRY(ctx, hipGraphLaunch(pl->gexec, st));
+    } else {
+        const int rc = enqueue_run(pl, src, ev[2], ev[3]);
+        if (rc) return rc;
+    }
     HIP_TRY(ctx, hipEventRecord(ev[1], st));
     pl->runs++;
     pl->ran = true;

@@ -563,3 +563,31 @@ def test_fuzz_level_blocks_through_pages(ctx, seed):
     buf = w.finish()
     w.close()
     H.check_file(buf, ctx)
+
+
+def test_graph_replay_mode(monkeypatch):
+    """PQD_GRAPH=1: chain batches are captured once into a HIP graph and replayed; same results."""
+    monkeypatch.setenv("PQD_GRAPH", "1")
+    c = R.Context(0)
+    try:
+        rng = np.random.default_rng(77)
+        cols = [Column("a", N.INT32, [1]), Column("s", N.BYTE_ARRAY, [1]), Column("r.x", N.INT64, [2, 1])]
+        buf = H.build_file(cols, 20000, 20000, 6000, rng, p_null=0.2, str_len=(0, 20))
+        H.check_file(buf, c)
+        pf = R.ParquetFile(buf)
+        chunks, nc, pages, npg = pf.descriptors(0, pf.num_row_groups)
+        plan = R.Plan(c, chunks, nc, pages, npg, pf.address, pf.size)
+        d_src = N.decode.pqd_device_alloc(c.handle, pf.size)
+        try:
+            assert N.decode.pqd_copy_to_device(c.handle, d_src, pf.address, pf.size) == 0
+            for _ in range(3):  # the second and third run replay the captured graph
+                plan.run(d_src)
+            plan.sync()
+            o = H.oracle_file(buf, pf)
+            for k in range(nc):
+                H.assert_chunk_equal(o[(0, pf.columns[chunks[k].column][0])], plan.column(k), key=k)
+        finally:
+            N.decode.pqd_device_free(c.handle, d_src)
+            plan.close()
+    finally:
+        c.close()
