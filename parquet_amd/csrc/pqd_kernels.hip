@@ -1663,7 +1663,7 @@ __global__ void k_level_block_sizes(const u8* __restrict__ src, const PageRec* _
 // Validity bitmap and per-row offsets.  A row starts at every level with rep == 0 (every level when
 // the column is not repeated); its value offset is the number of def == max_def before it.
 //   k_rows_count   per tile of RT levels: row starts and non-null counts (+ validity words)
-//   k_rows_scan    one wave per chunk: exclusive scan of the tile counts
+//   k_rows_scan    one block per chunk: exclusive scan of the tile counts
 //   k_rows_write   per tile: writes row_level_off / row_value_off
 // =====================================================================================
 static __device__ __forceinline__ u32 eq_mask16(u32x4 v, u32 level) {
@@ -1750,9 +1750,10 @@ __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunk
     }
 }
 
-__global__ __launch_bounds__(64) void k_rows_scan(const ChunkRec* __restrict__ chunks, const u32* __restrict__ rtile_prefix,
-                                                  const u32* __restrict__ chunk_ids, u32 n_rchunks,
-                                                  RowTile* __restrict__ tiles, ChunkDyn* __restrict__ chunk_dyn) {
+__global__ __launch_bounds__(1024) void k_rows_scan(const ChunkRec* __restrict__ chunks, const u32* __restrict__ rtile_prefix,
+                                                    const u32* __restrict__ chunk_ids, u32 n_rchunks,
+                                                    RowTile* __restrict__ tiles, ChunkDyn* __restrict__ chunk_dyn) {
+    __shared__ u64 s_r[16], s_v[16];
     const u32 k = blockIdx.x;
     if (k >= n_rchunks) return;
     const u32 c = chunk_ids[k];
@@ -1761,28 +1762,37 @@ __global__ __launch_bounds__(64) void k_rows_scan(const ChunkRec* __restrict__ c
         if (threadIdx.x == 0) chunk_dyn[c].n_rows = C.n_levels;
         return;
     }
+    // every thread owns a contiguous slice of the chunk's tiles: slice sums, block scan, slice bases
     const u32 t0 = rtile_prefix[k], t1 = rtile_prefix[k + 1];
-    const u32 lane = threadIdx.x;
-    u64 run_r = 0, run_v = 0;
-    for (u32 base = t0; base < t1; base += 64) {
-        const u32 t = base + lane;
-        u64 r = 0, v = 0;
-        if (t < t1) { r = tiles[t].rows; v = tiles[t].vals; }
-        u64 sr = r, sv = v;
-        for (int d = 1; d < 64; d <<= 1) {
-            const u64 tr = __shfl_up(sr, d), tv = __shfl_up(sv, d);
-            if (lane >= (u32)d) { sr += tr; sv += tv; }
-        }
-        if (t < t1) { tiles[t].row_base = run_r + sr - r; tiles[t].val_base = run_v + sv - v; }
-        run_r += __shfl(sr, 63);
-        run_v += __shfl(sv, 63);
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 per = (t1 - t0 + 1023) / 1024;
+    const u32 a = t0 + tid * per < t1 ? t0 + tid * per : t1, b = a + per < t1 ? a + per : t1;
+    u64 r = 0, v = 0;
+    for (u32 t = a; t < b; t++) { r += tiles[t].rows; v += tiles[t].vals; }
+    u64 sr = r, sv = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 tr = __shfl_up(sr, d), tv = __shfl_up(sv, d);
+        if (lane >= (u32)d) { sr += tr; sv += tv; }
     }
-    if (lane == 0) {
-        chunk_dyn[c].n_rows = run_r;
-        if (C.max_rep > 0) {
-            ((u64*)C.row_level_off)[run_r] = C.n_levels;
-            ((u64*)C.row_value_off)[run_r] = run_v;
-        }
+    if (lane == 63) { s_r[wv] = sr; s_v[wv] = sv; }
+    __syncthreads();
+    u64 base_r = 0, base_v = 0, tot_r = 0, tot_v = 0;
+    for (u32 q = 0; q < 16; q++) {
+        if (q < wv) { base_r += s_r[q]; base_v += s_v[q]; }
+        tot_r += s_r[q]; tot_v += s_v[q];
+    }
+    u64 run_r = base_r + sr - r, run_v = base_v + sv - v;
+    for (u32 t = a; t < b; t++) {
+        const u32 tr = tiles[t].rows, tv = tiles[t].vals;
+        tiles[t].row_base = run_r;
+        tiles[t].val_base = run_v;
+        run_r += tr;
+        run_v += tv;
+    }
+    if (tid == 0) {
+        chunk_dyn[c].n_rows = tot_r;
+        ((u64*)C.row_level_off)[tot_r] = C.n_levels;
+        ((u64*)C.row_value_off)[tot_r] = tot_v;
     }
 }
 
@@ -1911,7 +1921,7 @@ hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_
         hipLaunchKernelGGL((k_rows<false>), dim3(n_rtiles), dim3(256), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_rows_scan, dim3(n_rchunks), dim3(64), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles, chunk_dyn);
+    hipLaunchKernelGGL(k_rows_scan, dim3(n_rchunks), dim3(1024), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles, chunk_dyn);
     LAUNCH_CHECK();
     if (n_rtiles) {
         hipLaunchKernelGGL((k_rows<true>), dim3(n_rtiles), dim3(256), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles);
