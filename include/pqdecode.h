@@ -160,6 +160,16 @@ int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
 int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block, size_t block_len,
                    int out_elem_size, void* out_host, size_t max_values, int64_t* n_decoded);
 
+/* ---- standalone level ENCODE: rle.(*RLE).Write + Bytes (internal/rle/rle.go:48-156) for one block ----
+ * The mirror of pqd_rle_decode and the first piece of the write path: `levels` (one byte each, host memory)
+ * become int32 LE length + hybrid runs, byte for byte what the reference encoder writes: at a group
+ * boundary eight equal values open an RLE run that absorbs every following equal value, other values are
+ * bit-packed in groups of eight (the last one zero padded) under headers of at most 63 groups.
+ * width 0..8 (the reference packs widths 1..4 only; 5..8 follow the format text).  *out_len receives the
+ * encoded size even when `out_cap` is too small (PQD_E_ARG then). */
+int pqd_rle_encode(pqd_ctx* ctx, int width, const void* levels_host, size_t n, void* out_host, size_t out_cap,
+                   int64_t* out_len);
+
 /* ---- SNAPPY pages: pageData's SNAPPY arm (fields.go:361-371, snappy.Decode of golang/snappy) ------
  * pqd_decode handles SNAPPY chunks by itself; these are its steps for callers that keep the file on
  * the device.  A block is one page payload in snappy's raw block format (uvarint decoded length, then

@@ -1067,4 +1067,58 @@ int pqd_level_block_sizes(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_c
     return PQD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Level ENCODE, the mirror of pqd_rle_decode: rle.(*RLE).Write + Bytes (internal/rle/rle.go:48-156).
+int pqd_rle_encode(pqd_ctx* ctx, int width, const void* levels_host, size_t n, void* out_host, size_t out_cap, int64_t* out_len) {
+    if (!ctx || (!levels_host && n) || !out_len || width < 0 || width > 8) return PQD_E_ARG;
+    if (n > 0x7ffffff0u) return fail(ctx, PQD_E_ARG, "too many levels");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const u32 n_tiles = (u32)((n + EN_T - 1) / EN_T);
+    const u32 slots = (u32)(n / 8 + 2);
+    // every element is at most 5 header bytes + 1 value byte or 1 header byte + `width` bytes
+    const size_t out_bound = 4 + (size_t)slots * (size_t)(width > 5 ? width + 1 : 6);
+    ArenaPlan ap;
+    const size_t o_src = ap.take(n + 64);
+    const size_t o_blk = ap.take(sizeof(EncBlock));
+    const size_t o_tp = ap.take(8), o_ep = ap.take(8);
+    const size_t o_lead = ap.take((size_t)n_tiles * 4), o_ext = ap.take(((size_t)n_tiles + 1) * 4);
+    const size_t o_exits = ap.take((size_t)n_tiles * EN_E * 8);
+    const size_t o_ne = ap.take(4), o_ol = ap.take(4);
+    const size_t o_el = ap.take((size_t)slots * 4), o_ek = ap.take((size_t)slots * 4), o_eo = ap.take((size_t)slots * 4);
+    const size_t o_out = ap.take(out_bound + 64);
+    const size_t o_ent = ap.take((size_t)n_tiles * 8);
+    u8* A = nullptr;
+    hipError_t e = hipMalloc((void**)&A, ap.total);
+    if (e != hipSuccess) return fail(ctx, PQD_E_NOMEM, "hipMalloc failed", e);
+    struct Free { u8* p; ~Free() { (void)hipFree(p); } } fr{A};
+    EncBlock B;
+    memset(&B, 0, sizeof B);
+    B.src_off = 0; B.n = (u32)n; B.width = (u32)width; B.elem_base = 0; B.out = A + o_out;
+    const u32 tp[2] = {0, n_tiles}, ep[2] = {0, slots};
+    HIP_TRY(ctx, hipMemsetAsync(A + o_ent, 0xFF, (size_t)n_tiles * 8 + 1, st));
+    HIP_TRY(ctx, hipMemsetAsync(A + o_ext, 0, ((size_t)n_tiles + 1) * 4, st));
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(A + o_src, levels_host, n, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_blk, &B, sizeof B, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_tp, tp, 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_ep, ep, 8, hipMemcpyHostToDevice, st));
+    EncArgs a;
+    a.blocks = (EncBlock*)(A + o_blk); a.tile_prefix = (u32*)(A + o_tp); a.elem_prefix = (u32*)(A + o_ep);
+    a.n_blocks = 1; a.n_tiles = n_tiles; a.elem_slots = slots;
+    a.lead = (u32*)(A + o_lead); a.ext = (u32*)(A + o_ext); a.exits = A + o_exits; a.entries = A + o_ent;
+    a.n_elems = (u32*)(A + o_ne); a.out_len = (u32*)(A + o_ol);
+    a.elems = (u32*)(A + o_el); a.elem_k = (u32*)(A + o_ek); a.elem_off = (u32*)(A + o_eo);
+    HIP_TRY(ctx, launch_rle_encode(st, A + o_src, a));
+    u32 L = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&L, A + o_ol, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    *out_len = (int64_t)L + 4;
+    if ((size_t)L + 4 > out_bound) return fail(ctx, PQD_E_CORRUPT, "encoder overran its bound");
+    if ((size_t)L + 4 > out_cap) return fail(ctx, PQD_E_ARG, "destination too small");
+    if (!out_host) return PQD_E_ARG;
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, A + o_out, (size_t)L + 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return PQD_OK;
+}
+
 }  // extern "C"

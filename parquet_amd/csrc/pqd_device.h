@@ -146,4 +146,29 @@ hipError_t launch_snappy_tiles(hipStream_t st, const u8* src, const Region* regi
 hipError_t launch_level_block_sizes(hipStream_t st, const u8* src, const PageRec* pages, const ChunkRec* chunks, u32 n_pages,
                                     int* sizes);
 
+// ---- level encoder (pqd_encode.hip) ----------------------------------------------------------
+constexpr u32 EN_T = 2048;  // level positions per encoder tile
+constexpr u32 EN_E = 9;     // chain entries per tile: its first 8 positions + the end of a run that reaches into it
+struct EncBlock {
+    u64 src_off;    // first level of the block (4-byte aligned)
+    u32 n;          // levels
+    u32 width;      // bit width, 0..8
+    u32 elem_base;  // first slot of the block in the element arrays (n / 8 + 2 slots)
+    u32 pad;
+    u8* out;        // int32 length + runs go here
+};
+struct EncArgs {
+    const EncBlock* blocks;
+    const u32* tile_prefix;  // n_blocks + 1
+    const u32* elem_prefix;  // n_blocks + 1 (== elem_base of every block, then the total)
+    u32 n_blocks, n_tiles, elem_slots;
+    u32* lead;               // n_tiles
+    u32* ext;                // n_tiles + 1
+    void* exits;             // n_tiles * EN_E * 8 bytes
+    void* entries;           // n_tiles * 8 bytes, reset to 0xFF
+    u32 *n_elems, *out_len;  // n_blocks
+    u32 *elems, *elem_k, *elem_off;  // elem_slots each
+};
+hipError_t launch_rle_encode(hipStream_t st, const u8* src, const EncArgs& a);
+
 }  // namespace pqd

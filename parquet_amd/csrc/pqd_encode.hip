@@ -1,0 +1,360 @@
+// Hybrid RLE / bit-packed level ENCODER on the device: the mirror of the decode path, byte for byte what
+// rle.(*RLE) produces (internal/rle/rle.go:48-156: Write :48-67, writeOrAppendBitPackedRun :69-85,
+// endPreviousBitPackedRun :87-96, writeRLERun :98-109, Bytes :140-156).
+//
+// What the reference's per-value state machine does, seen from a distance: at a group boundary, eight
+// equal values open an RLE run that absorbs every following equal value; otherwise the next eight values
+// (zero padded at the end of the input) become one bit-packed group, and consecutive groups share a
+// header of at most 63 groups.  So the boundaries form a chain over the level positions,
+//     next(i) = end of the equal run of i   if v[i..i+8) are all equal,      i + 8 otherwise,
+// and, as in the decoder, a chain is turned into parallel work with tiles and exit tables.  A tile is
+// EN_T positions.  The chain can enter a tile at its first 8 positions (a group stepped over the tile
+// boundary) or where an RLE run that began earlier ends, which is one data-defined position per tile:
+// 9 entries.
+//   k_enc_lead     per tile: how far the equal run of the previous tile's last value reaches into it
+//   k_enc_ext      per block: the same, continued across whole tiles (one backward pass over the tiles)
+//   k_enc_exits    per tile, one lane per entry: where the chain leaves the tile, elements passed
+//   k_enc_hop      per block: true entry and element index of every tile
+//   k_enc_mark     per tile: walks the true chain, one record per element (position, RLE flag)
+//   k_enc_layout   per block: byte offset of every element (max-scan for the bit-packed group index
+//                  inside its run of at most 63, then a sum-scan of the element sizes)
+//   k_enc_write    per element: header / value bytes or the packed group; block length in front
+#include "pqd_device.h"
+
+namespace pqd {
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// End (exclusive) of the equal run that position p of the tile belongs to, from the tile's change masks:
+// bit k of s_mask[l] is set when v[tb + 32 l + k] != v[tb + 32 l + k + 1] (the last value of the block
+// counts as changed).  s_next[l] = first lane >= l with a nonzero mask (64 if none).  Returns EN_T when
+// the run reaches the end of the tile.
+static __device__ __forceinline__ u32 run_end_in_tile(const u32* s_mask, const u32* s_next, u32 rel) {
+    const u32 l = rel >> 5, k = rel & 31;
+    const u32 m = s_mask[l] >> k;
+    if (m) return rel + (u32)__builtin_ctz(m) + 1;
+    if (l == 63) return EN_T;
+    const u32 l2 = s_next[l + 1];
+    if (l2 >= 64) return EN_T;
+    return l2 * 32 + (u32)__builtin_ctz(s_mask[l2]) + 1;
+}
+
+// Builds the change masks of a tile in LDS (all 64 lanes of the wave take part).
+static __device__ __forceinline__ void build_masks(const u8* v, u32 n, u32 tb, u32 lane, u32* s_mask, u32* s_next) {
+    // my 32 values and the first value of the next lane
+    const u32 p0 = tb + lane * 32;
+    u32 w[9];
+#pragma unroll
+    for (int d = 0; d < 9; d++) {
+        const u32 p = p0 + 4 * d;
+        u32 x = 0;
+        if (p + 4 <= n) x = *(const u32*)(v + p);  // v + tb is 4-byte aligned (tiles and blocks are)
+        else for (u32 k = 0; p + k < n && k < 4; k++) x |= (u32)v[p + k] << (8 * k);
+        w[d] = x;
+    }
+    u32 mask = 0;
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const u32 a = (w[k >> 2] >> (8 * (k & 3))) & 0xFF, b = (w[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xFF;
+        const u32 p = p0 + k;
+        // the last value of the block ends its run; positions past the block never matter
+        const bool ch = p + 1 >= n ? p + 1 == n : a != b;
+        mask |= (u32)ch << k;
+    }
+    s_mask[lane] = mask;
+    // first lane >= me with a nonzero mask: reverse min-scan
+    u32 nx = mask ? lane : 64;
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_down(nx, d);
+        if (lane + d < 64 && t < nx) nx = t;
+    }
+    s_next[lane] = nx;
+}
+
+}  // namespace
+
+// lead[t] = number of leading positions of tile t (t > 0) equal to the last value of tile t - 1
+__global__ __launch_bounds__(64) void k_enc_lead(const u8* __restrict__ src, const EncBlock* __restrict__ blocks,
+                                                 const u32* __restrict__ tile_prefix, u32 n_blocks, u32* __restrict__ lead) {
+    const u32 tile = blockIdx.x, lane = threadIdx.x;
+    u32 lo = 0, hi = n_blocks;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (tile_prefix[mid] <= tile) lo = mid; else hi = mid; }
+    const EncBlock B = blocks[lo];
+    const u32 t = tile - tile_prefix[lo], tb = t * EN_T;
+    if (t == 0) { if (lane == 0) lead[tile] = 0; return; }
+    const u8* v = src + B.src_off;
+    const u32 n = B.n, ref = v[tb - 1];
+    u32 first = EN_T;  // first position (tile relative) that differs from ref
+    for (u32 base = 0; base < EN_T && first == EN_T; base += 64 * 4) {
+        const u32 p = tb + base + lane * 4;
+        u32 x = ref * 0x01010101u;  // positions past the block compare equal; the result is clamped below
+        if (p + 4 <= n) x = *(const u32*)(v + p);
+        else for (u32 k = 0; k < 4 && p + k < n; k++) x = (x & ~(0xFFu << (8 * k))) | ((u32)v[p + k] << (8 * k));
+        const u32 diff = x ^ (ref * 0x01010101u);
+        u32 k = 4;
+        if (diff) k = (u32)__builtin_ctz(diff) >> 3;
+        const u64 b = __ballot(k < 4);
+        if (b) {
+            const int l = __ffsll((unsigned long long)b) - 1;
+            first = base + (u32)l * 4 + __shfl(k, l);
+        }
+    }
+    const u32 in_tile = n - tb < EN_T ? n - tb : EN_T;
+    if (lane == 0) lead[tile] = first < in_tile ? first : in_tile;
+}
+
+// ext[t] = how far the equal run that reaches the end of tile t - 1 goes on from the start of tile t,
+// across as many whole tiles as it covers
+__global__ void k_enc_ext(const EncBlock* __restrict__ blocks, const u32* __restrict__ tile_prefix, u32 n_blocks,
+                          const u32* __restrict__ lead, u32* __restrict__ ext) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const u32 t0 = tile_prefix[b], t1 = tile_prefix[b + 1];
+    u32 carry = 0;
+    for (u32 t = t1; t-- > t0;) {
+        const u32 l = lead[t];
+        const u32 e = l == EN_T ? EN_T + carry : l;  // a tile covered entirely hands over to the next one
+        ext[t] = e;
+        carry = e;
+    }
+}
+
+// One element step at block position p (tile relative rel): returns the next boundary (block position).
+static __device__ __forceinline__ u32 enc_step(const u32* s_mask, const u32* s_next, const u32* __restrict__ ext_next, u32 tb,
+                                               u32 rel, u32 n, bool& rle) {
+    const u32 p = tb + rel;
+    u32 re = run_end_in_tile(s_mask, s_next, rel);  // tile relative, EN_T = reaches the end of the tile
+    u32 end = tb + re;
+    if (re == EN_T && tb + EN_T < n) end = tb + EN_T + *ext_next;
+    if (end > n) end = n;
+    rle = p + 8 <= n && end - p >= 8;
+    return rle ? end : p + 8;
+}
+
+struct EncExit { u32 pos; u32 cnt; };
+
+__global__ __launch_bounds__(64) void k_enc_exits(const u8* __restrict__ src, const EncBlock* __restrict__ blocks,
+                                                  const u32* __restrict__ tile_prefix, u32 n_blocks,
+                                                  const u32* __restrict__ lead, const u32* __restrict__ ext,
+                                                  EncExit* __restrict__ exits) {
+    __shared__ u32 s_mask[64], s_next[64];
+    const u32 tile = blockIdx.x, lane = threadIdx.x;
+    u32 lo = 0, hi = n_blocks;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (tile_prefix[mid] <= tile) lo = mid; else hi = mid; }
+    const EncBlock B = blocks[lo];
+    const u32 t = tile - tile_prefix[lo], tb = t * EN_T, n = B.n;
+    const u32 te = tb + EN_T;
+    build_masks(src + B.src_off, n, tb, lane, s_mask, s_next);
+    __syncthreads();
+    if (lane >= EN_E) return;
+    // entries 0..7: the first 8 positions; entry 8: where the run of the previous tile's last value ends
+    u32 p = lane < 8 ? tb + lane : tb + lead[tile];
+    if (lane == 8 && (lead[tile] < 8 || lead[tile] >= EN_T)) p = 0xFFFFFFFFu;  // covered by entries 0..7 / no entry
+    u32 cnt = 0;
+    const u32* ext_next = ext + tile + 1;  // the array has one spare entry
+    while (p < te && p < n) {
+        bool rle;
+        p = enc_step(s_mask, s_next, ext_next, tb, p - tb, n, rle);
+        cnt++;
+    }
+    EncExit x;
+    x.pos = p; x.cnt = cnt;
+    exits[(u64)tile * EN_E + lane] = x;
+}
+
+// True entry (block position, element index) of every tile; total elements of the block.
+__global__ void k_enc_hop(const EncBlock* __restrict__ blocks, const u32* __restrict__ tile_prefix, u32 n_blocks,
+                          const u32* __restrict__ lead, const EncExit* __restrict__ exits, EncExit* __restrict__ entries,
+                          u32* __restrict__ n_elems) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const u32 n = blocks[b].n, t0 = tile_prefix[b];
+    u32 p = 0, cnt = 0;
+    while (p < n) {
+        const u32 t = p / EN_T, off = p - t * EN_T;
+        EncExit e;
+        e.pos = p; e.cnt = cnt;
+        entries[t0 + t] = e;
+        const EncExit x = exits[(u64)(t0 + t) * EN_E + (off < 8 ? off : 8)];  // off >= 8 is the run end: entry 8
+        p = x.pos;
+        cnt += x.cnt;
+    }
+    n_elems[b] = cnt;
+}
+
+// Element records: position | RLE flag in bit 31 (levels per block stay below 2^31).
+__global__ __launch_bounds__(64) void k_enc_mark(const u8* __restrict__ src, const EncBlock* __restrict__ blocks,
+                                                 const u32* __restrict__ tile_prefix, u32 n_blocks,
+                                                 const u32* __restrict__ ext, const EncExit* __restrict__ entries,
+                                                 u32* __restrict__ elems) {
+    __shared__ u32 s_mask[64], s_next[64];
+    const u32 tile = blockIdx.x, lane = threadIdx.x;
+    const EncExit ent = entries[tile];
+    if (ent.pos == 0xFFFFFFFFu) return;  // the true chain has no boundary in this tile
+    u32 lo = 0, hi = n_blocks;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (tile_prefix[mid] <= tile) lo = mid; else hi = mid; }
+    const EncBlock B = blocks[lo];
+    const u32 t = tile - tile_prefix[lo], tb = t * EN_T, n = B.n, te = tb + EN_T;
+    build_masks(src + B.src_off, n, tb, lane, s_mask, s_next);
+    __syncthreads();
+    if (lane != 0) return;
+    u32* out = elems + B.elem_base + ent.cnt;
+    u32 p = ent.pos, i = 0;
+    while (p < te && p < n) {
+        bool rle;
+        const u32 q = enc_step(s_mask, s_next, ext + tile + 1, tb, p - tb, n, rle);
+        out[i++] = p | (rle ? 0x80000000u : 0u);
+        p = q;
+    }
+}
+
+// Byte offset of every element of a block, one workgroup per block.
+//   bit-packed element e: k = e - 1 - (index of the last RLE element before e); it opens a header when
+//   k % 63 == 0 (writeOrAppendBitPackedRun: a new run after an RLE run or after 63 groups)
+//   sizes: RLE = leb128(count << 1) + one value byte unless width is 0; bit-packed = width bytes (+1 header)
+__global__ __launch_bounds__(1024) void k_enc_layout(const EncBlock* __restrict__ blocks, const u32* __restrict__ n_elems,
+                                                     const u32* __restrict__ elems, u32* __restrict__ elem_k,
+                                                     u32* __restrict__ elem_off, u32* __restrict__ out_len) {
+    __shared__ int s_last[16];
+    __shared__ u32 s_sum[16];
+    const EncBlock B = blocks[blockIdx.x];
+    const u32 ne = n_elems[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32* el = elems + B.elem_base;
+    u32* ek = elem_k + B.elem_base;
+    u32* eo = elem_off + B.elem_base;
+    const u32 bw = B.width ? 1u : 0u;
+    int carry_last = -1;  // index of the last RLE element before the current batch
+    u32 carry_off = 0;
+    for (u32 base = 0; base < ne; base += 1024) {
+        const u32 e = base + tid;
+        const bool valid = e < ne;
+        const u32 rec = valid ? el[e] : 0;
+        const bool rle = valid && (rec & 0x80000000u);
+        // inclusive max-scan of (rle ? e : -1)
+        int last = rle ? (int)e : -1;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(last, d);
+            if (lane >= (u32)d && t > last) last = t;
+        }
+        if (lane == 63) s_last[wv] = last;
+        __syncthreads();
+        int pre = carry_last;
+        for (u32 q = 0; q < wv; q++) pre = s_last[q] > pre ? s_last[q] : pre;
+        int blk_last = carry_last;
+        for (u32 q = 0; q < 16; q++) blk_last = s_last[q] > blk_last ? s_last[q] : blk_last;
+        last = last > pre ? last : pre;  // index of the last RLE element at or before e
+        u32 size = 0, k = 0;
+        if (valid) {
+            if (rle) {
+                const u32 nextp = e + 1 < ne ? (el[e + 1] & 0x7FFFFFFFu) : B.n;
+                const u32 h = (nextp - (rec & 0x7FFFFFFFu)) << 1;  // a run is shorter than 2^31 values
+                size = (h < (1u << 7) ? 1u : h < (1u << 14) ? 2u : h < (1u << 21) ? 3u : h < (1u << 28) ? 4u : 5u) + bw;
+            } else {
+                k = e - 1 - (u32)last;  // last == -1: e
+                size = B.width + (k % 63 == 0 ? 1u : 0u);
+            }
+            ek[e] = k;
+        }
+        // exclusive sum-scan of the sizes
+        u32 incl = size;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(incl, d);
+            if (lane >= (u32)d) incl += t;
+        }
+        if (lane == 63) s_sum[wv] = incl;
+        __syncthreads();
+        u32 pre_s = carry_off, tot = 0;
+        for (u32 q = 0; q < 16; q++) {
+            if (q < wv) pre_s += s_sum[q];
+            tot += s_sum[q];
+        }
+        if (valid) eo[e] = pre_s + incl - size;
+        carry_off += tot;
+        carry_last = blk_last;
+        __syncthreads();
+    }
+    if (tid == 0) out_len[blockIdx.x] = carry_off;
+}
+
+// bitpack.Pack for one group (internal/bitpack/bitpack.go:20-74, generated by cmd/bitpackgen: value j
+// occupies bits [j*w, (j+1)*w) of the group's w bytes, LSB first)
+static __device__ __forceinline__ void pack_group(const u8* v, u32 p, u32 n, u32 w, u8* out) {
+    u64 acc = 0;
+    const u64 mask = (1ull << w) - 1;
+    for (u32 j = 0; j < 8; j++) {
+        const u64 x = p + j < n ? v[p + j] : 0;  // the last group is zero padded
+        acc |= (x & mask) << (j * w);
+    }
+    for (u32 b = 0; b < w; b++) out[b] = (u8)(acc >> (8 * b));
+}
+
+__global__ __launch_bounds__(256) void k_enc_write(const u8* __restrict__ src, const EncBlock* __restrict__ blocks,
+                                                   const u32* __restrict__ elem_prefix, u32 n_blocks,
+                                                   const u32* __restrict__ n_elems, const u32* __restrict__ elems,
+                                                   const u32* __restrict__ elem_k, const u32* __restrict__ elem_off,
+                                                   const u32* __restrict__ out_len) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;  // slot in the element arrays
+    u32 lo = 0, hi = n_blocks;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (elem_prefix[mid] <= g) lo = mid; else hi = mid; }
+    const EncBlock B = blocks[lo];
+    const u32 e = g - elem_prefix[lo], ne = n_elems[lo];
+    u8* out = B.out;
+    if (e == 0) {  // int32 LE length in front of the runs (rle.go:153-155); also for an empty block
+        const u32 L = out_len[lo];
+        out[0] = (u8)L; out[1] = (u8)(L >> 8); out[2] = (u8)(L >> 16); out[3] = (u8)(L >> 24);
+    }
+    if (e >= ne) return;
+    const u8* v = src + B.src_off;
+    const u32* el = elems + B.elem_base;
+    const u32 rec = el[e], p = rec & 0x7FFFFFFFu, off = elem_off[B.elem_base + e];
+    u8* o = out + 4 + off;
+    if (rec & 0x80000000u) {
+        const u32 nextp = e + 1 < ne ? (el[e + 1] & 0x7FFFFFFFu) : B.n;
+        u32 h = (nextp - p) << 1;
+        while (h >= 0x80) { *o++ = (u8)(h | 0x80); h >>= 7; }
+        *o++ = (u8)h;
+        if (B.width) *o = v[p];
+    } else {
+        const u32 k = elem_k[B.elem_base + e], kk = k % 63;
+        if (kk == 0) o++;  // the header byte of the run this group opens
+        pack_group(v, p, B.n, B.width, o);
+        // the last group of a bit-packed run writes the run's header: groups << 1 | 1
+        const bool last = kk == 62 || e + 1 == ne || (el[e + 1] & 0x80000000u);
+        if (last) out[4 + elem_off[B.elem_base + e - kk]] = (u8)(((kk + 1) << 1) | 1);
+    }
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+#define ENC_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t launch_rle_encode(hipStream_t st, const u8* src, const EncArgs& a) {
+    if (a.n_blocks == 0) return hipSuccess;
+    if (a.n_tiles) {
+        hipLaunchKernelGGL(k_enc_lead, dim3(a.n_tiles), dim3(64), 0, st, src, a.blocks, a.tile_prefix, a.n_blocks, a.lead);
+        ENC_CHECK();
+        hipLaunchKernelGGL(k_enc_ext, dim3((a.n_blocks + 63) / 64), dim3(64), 0, st, a.blocks, a.tile_prefix, a.n_blocks, a.lead, a.ext);
+        ENC_CHECK();
+        hipLaunchKernelGGL(k_enc_exits, dim3(a.n_tiles), dim3(64), 0, st, src, a.blocks, a.tile_prefix, a.n_blocks, a.lead, a.ext,
+                           (EncExit*)a.exits);
+        ENC_CHECK();
+    }
+    hipLaunchKernelGGL(k_enc_hop, dim3((a.n_blocks + 63) / 64), dim3(64), 0, st, a.blocks, a.tile_prefix, a.n_blocks, a.lead,
+                       (const EncExit*)a.exits, (EncExit*)a.entries, a.n_elems);
+    ENC_CHECK();
+    if (a.n_tiles) {
+        hipLaunchKernelGGL(k_enc_mark, dim3(a.n_tiles), dim3(64), 0, st, src, a.blocks, a.tile_prefix, a.n_blocks, a.ext,
+                           (const EncExit*)a.entries, a.elems);
+        ENC_CHECK();
+    }
+    hipLaunchKernelGGL(k_enc_layout, dim3(a.n_blocks), dim3(1024), 0, st, a.blocks, a.n_elems, a.elems, a.elem_k, a.elem_off, a.out_len);
+    ENC_CHECK();
+    const u32 slots = a.elem_slots ? a.elem_slots : 1;
+    hipLaunchKernelGGL(k_enc_write, dim3((slots + 255) / 256), dim3(256), 0, st, src, a.blocks, a.elem_prefix, a.n_blocks, a.n_elems,
+                       a.elems, a.elem_k, a.elem_off, a.out_len);
+    ENC_CHECK();
+    return hipSuccess;
+}
+
+}  // namespace pqd

@@ -278,6 +278,17 @@ def rle_decode(ctx, width, block, max_values, elem_size=1):
     return out[:min(n.value, max_values)], n.value
 
 
+def rle_encode(ctx, width, levels):
+    """rle.(*RLE).Write + Bytes on the device: levels (uint8) -> int32 length + hybrid runs (bytes)."""
+    lv = np.ascontiguousarray(levels, np.uint8)
+    cap = 4 + (lv.size // 8 + 2) * max(width + 1, 6)
+    out = np.zeros(cap, np.uint8)
+    n = C.c_int64()
+    rc = N.decode.pqd_rle_encode(ctx.handle, width, lv.ctypes.data if lv.size else None, lv.size, out.ctypes.data, cap, C.byref(n))
+    _check(rc, ctx.handle)
+    return out[:n.value].tobytes()
+
+
 class Levels:
     """template.go:295-299"""
 
