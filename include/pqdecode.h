@@ -170,6 +170,34 @@ int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block, size_t block_len,
 int pqd_rle_encode(pqd_ctx* ctx, int width, const void* levels_host, size_t n, void* out_host, size_t out_cap,
                    int64_t* out_len);
 
+/* ---- page payloads of the write path (RequiredField.DoWrite fields.go:95-111, OptionalField.DoWrite
+ * fields.go:232-271, codec UNCOMPRESSED): per page [repetition levels][definition levels][PLAIN values],
+ * the levels through the encoder above, the values as the generated Write methods serialise them
+ * (binary.Write little endian: template_required.go:37-49, template_optional.go:96-114; bools 8 per byte
+ * LSB first: template_bool.go; strings int32 length + bytes: template_string.go:62-78).  The host frames
+ * the payloads with thrift page headers, as the reference does. */
+typedef struct {
+    int32_t phys_type;
+    int32_t is_unsigned;  /* converted type UINT_32 / UINT_64: statistics compare unsigned */
+    int32_t max_def, max_rep;
+    int64_t n_levels;     /* len(Defs); for a required column the number of values */
+    int64_t n_values;     /* non-null values */
+    int64_t defs_off, reps_off; /* uint8 per level, offsets into `src`, 4-byte aligned; ignored when the max level is 0 */
+    int64_t values_off;   /* dense little-endian values (aligned to their width), one byte per bool, or the string bytes */
+    int64_t offsets_off;  /* strings: int32[n_values + 1] into the string bytes, 4-byte aligned */
+} pqd_enc_page;
+typedef struct {
+    int64_t payload_off, payload_len; /* where the page payload lies in `out` */
+    int32_t rep_bytes, def_bytes;     /* the repLen / defLen DoWrite hands to WritePageHeader */
+    int64_t null_count;               /* levels below max_def (the nils of the generated stats types) */
+    uint8_t min[8], max[8];           /* fixed-width types: as the stats types keep them (min from the type's
+                                         maximum, max from ZERO: template_required.go:77-96) */
+    int32_t minmax_len;               /* 4 / 8, or 0 = Min()/Max() return nil (no non-null value; bools, strings) */
+    int32_t reserved;
+} pqd_enc_result;
+int pqd_encode_pages(pqd_ctx* ctx, const pqd_enc_page* pages, size_t n, const void* src_host, size_t src_len,
+                     void* out_host, size_t out_cap, pqd_enc_result* results, int64_t* out_len);
+
 /* ---- SNAPPY pages: pageData's SNAPPY arm (fields.go:361-371, snappy.Decode of golang/snappy) ------
  * pqd_decode handles SNAPPY chunks by itself; these are its steps for callers that keep the file on
  * the device.  A block is one page payload in snappy's raw block format (uvarint decoded length, then

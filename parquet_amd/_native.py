@@ -33,6 +33,18 @@ class SnappyBlock(C.Structure):
                 ("hdr_len", C.c_int32), ("reserved", C.c_int32)]
 
 
+class EncPage(C.Structure):
+    _fields_ = [("phys_type", C.c_int32), ("is_unsigned", C.c_int32), ("max_def", C.c_int32), ("max_rep", C.c_int32),
+                ("n_levels", C.c_int64), ("n_values", C.c_int64), ("defs_off", C.c_int64), ("reps_off", C.c_int64),
+                ("values_off", C.c_int64), ("offsets_off", C.c_int64)]
+
+
+class EncResult(C.Structure):
+    _fields_ = [("payload_off", C.c_int64), ("payload_len", C.c_int64), ("rep_bytes", C.c_int32), ("def_bytes", C.c_int32),
+                ("null_count", C.c_int64), ("min", C.c_uint8 * 8), ("max", C.c_uint8 * 8), ("minmax_len", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class PageDesc(C.Structure):
     _fields_ = [("src_off", C.c_int64), ("payload_len", C.c_int32), ("num_values", C.c_int32),
                 ("rep_bytes", C.c_int32), ("def_bytes", C.c_int32)]
@@ -75,6 +87,7 @@ DECODE_SYMBOLS = {
                              _P, C.c_size_t, C.POINTER(_P)]),
     "pqd_rle_decode": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int, _P, C.c_size_t, C.POINTER(C.c_int64)]),
     "pqd_rle_encode": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_int64)]),
+    "pqd_encode_pages": (C.c_int, [_P, C.POINTER(EncPage), C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(EncResult), C.POINTER(C.c_int64)]),
     "pqd_snappy_sizes": (C.c_int, [_P, C.c_size_t, C.POINTER(SnappyBlock), C.c_size_t]),
     "pqd_snappy_decode": (C.c_int, [_P, C.POINTER(SnappyBlock), C.c_size_t, _P, C.c_size_t, _P, C.c_size_t]),
     "pqd_level_block_sizes": (C.c_int, [_P, C.POINTER(ChunkDesc), C.c_size_t, C.POINTER(PageDesc), C.c_size_t, _P, C.c_size_t]),

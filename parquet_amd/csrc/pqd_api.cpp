@@ -1121,4 +1121,146 @@ int pqd_rle_encode(pqd_ctx* ctx, int width, const void* levels_host, size_t n, v
     return PQD_OK;
 }
 
+// Page payloads of the write path (RequiredField.DoWrite / OptionalField.DoWrite, fields.go:95-111, 232-271,
+// UNCOMPRESSED): [repetition levels][definition levels][PLAIN values] per page, plus the statistics the
+// generated stats types keep.  Host arrays in, host payloads out; everything in between runs on the device.
+int pqd_encode_pages(pqd_ctx* ctx, const pqd_enc_page* pages, size_t n, const void* src_host, size_t src_len, void* out_host,
+                     size_t out_cap, pqd_enc_result* results, int64_t* out_len) {
+    if (!ctx || (!pages && n) || (!src_host && src_len) || !results || !out_len) return PQD_E_ARG;
+    *out_len = 0;
+    if (n == 0) return PQD_OK;
+    if (n > 0x3fffffffu) return fail(ctx, PQD_E_ARG, "too many pages");
+    const u8* hs = (const u8*)src_host;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<EncPage> P(n);
+    std::vector<EncBlock> B;
+    std::vector<u32> tile_prefix(1, 0), elem_prefix(1, 0), chunk_prefix(1, 0);
+    size_t bound = 0;
+    auto add_block = [&](int64_t off, int64_t nl, int max_level) -> int {
+        if (off < 0 || (off & 3) || (u64)off + (u64)nl > src_len) return -1;
+        EncBlock b;
+        memset(&b, 0, sizeof b);
+        b.src_off = (u64)off; b.n = (u32)nl; b.width = (u32)bits_len((unsigned)max_level);
+        b.elem_base = elem_prefix.back();
+        const u64 slots = (u64)nl / 8 + 2, tiles = ((u64)nl + EN_T - 1) / EN_T;
+        if ((u64)elem_prefix.back() + slots > 0x7fffffffull || (u64)tile_prefix.back() + tiles > 0x7fffffffull) return -2;
+        elem_prefix.push_back(elem_prefix.back() + (u32)slots);
+        tile_prefix.push_back(tile_prefix.back() + (u32)tiles);
+        bound += 4 + (size_t)slots * (b.width > 5 ? b.width + 1 : 6);
+        B.push_back(b);
+        return (int)B.size() - 1;
+    };
+    for (size_t i = 0; i < n; i++) {
+        const pqd_enc_page& q = pages[i];
+        EncPage& e = P[i];
+        memset(&e, 0, sizeof e);
+        int w = 0;
+        switch (q.phys_type) {
+        case PQD_INT32: case PQD_FLOAT: w = 4; break;
+        case PQD_INT64: case PQD_DOUBLE: w = 8; break;
+        case PQD_BOOLEAN: case PQD_BYTE_ARRAY: break;
+        default: return fail(ctx, PQD_E_UNSUPPORTED, "unsupported physical type");
+        }
+        if (q.max_def < 0 || q.max_def > 255 || q.max_rep < 0 || q.max_rep > q.max_def || q.n_levels < 0 || q.n_values < 0 ||
+            q.n_levels > 0x7ffffff0 || q.n_values > 0x7ffffff0 || (q.max_def > 0 ? q.n_values > q.n_levels : q.n_values != q.n_levels))
+            return fail(ctx, PQD_E_ARG, "bad page description");
+        e.phys_type = q.phys_type; e.width = (u32)w; e.n_values = (u64)q.n_values;
+        e.stats_kind = (q.phys_type == PQD_FLOAT || q.phys_type == PQD_DOUBLE) ? 2u : q.is_unsigned ? 1u : 0u;
+        e.rep_block = e.def_block = 0xFFFFFFFFu;
+        if (q.max_rep > 0) {
+            const int r = add_block(q.reps_off, q.n_levels, q.max_rep);
+            if (r < 0) return fail(ctx, r == -1 ? PQD_E_ARG : PQD_E_UNSUPPORTED, "repetition levels: bad offset (4-byte aligned, inside the source) or batch too large");
+            e.rep_block = (u32)r;
+        }
+        if (q.max_def > 0) {
+            const int r = add_block(q.defs_off, q.n_levels, q.max_def);
+            if (r < 0) return fail(ctx, r == -1 ? PQD_E_ARG : PQD_E_UNSUPPORTED, "definition levels: bad offset (4-byte aligned, inside the source) or batch too large");
+            e.def_block = (u32)r;
+        }
+        u64 vb, units;
+        if (w) {
+            vb = (u64)q.n_values * (u64)w;
+            if (q.values_off < 0 || (q.values_off & (w - 1)) || (u64)q.values_off + vb > src_len) return fail(ctx, PQD_E_ARG, "values outside the source or misaligned");
+            units = (vb + ENC_VALUE_CHUNK - 1) / ENC_VALUE_CHUNK;
+        } else if (q.phys_type == PQD_BOOLEAN) {
+            vb = ((u64)q.n_values + 7) / 8;
+            if (q.values_off < 0 || (u64)q.values_off + (u64)q.n_values > src_len) return fail(ctx, PQD_E_ARG, "values outside the source");
+            units = (vb + ENC_VALUE_CHUNK - 1) / ENC_VALUE_CHUNK;
+        } else {
+            if (q.offsets_off < 0 || (q.offsets_off & 3) || (u64)q.offsets_off + 4 * ((u64)q.n_values + 1) > src_len)
+                return fail(ctx, PQD_E_ARG, "string offsets outside the source or misaligned");
+            const int32_t* offs = (const int32_t*)(hs + q.offsets_off);
+            for (int64_t k = 0; k < q.n_values; k++)
+                if (offs[k + 1] < offs[k]) return fail(ctx, PQD_E_ARG, "string offsets must not decrease");
+            if (offs[0] < 0 || q.values_off < 0 || (u64)q.values_off + (u64)offs[q.n_values] > src_len)
+                return fail(ctx, PQD_E_ARG, "string bytes outside the source");
+            vb = 4 * (u64)q.n_values + (u64)(offs[q.n_values] - offs[0]);
+            units = ((u64)q.n_values + ENC_VALUE_CHUNK / 16 - 1) / (ENC_VALUE_CHUNK / 16);
+        }
+        e.values_off = (u64)q.values_off; e.offsets_off = (u64)(q.offsets_off < 0 ? 0 : q.offsets_off);
+        if ((u64)chunk_prefix.back() + units > 0x7fffffffull) return fail(ctx, PQD_E_UNSUPPORTED, "batch too large");
+        chunk_prefix.push_back(chunk_prefix.back() + (u32)units);
+        bound += (size_t)vb;
+    }
+    const u32 nb = (u32)B.size(), n_tiles = tile_prefix.back(), slots = elem_prefix.back();
+    ArenaPlan ap;
+    const size_t o_src = ap.take(src_len + 64);
+    const size_t o_pg = ap.take(n * sizeof(EncPage)), o_blk = ap.take((size_t)nb * sizeof(EncBlock));
+    const size_t o_tp = ap.take(((size_t)nb + 1) * 4), o_ep = ap.take(((size_t)nb + 1) * 4), o_cp = ap.take((n + 1) * 4);
+    const size_t o_lead = ap.take((size_t)n_tiles * 4), o_ext = ap.take(((size_t)n_tiles + 1) * 4);
+    const size_t o_exits = ap.take((size_t)n_tiles * EN_E * 8), o_ent = ap.take((size_t)n_tiles * 8);
+    const size_t o_ne = ap.take((size_t)nb * 4), o_ol = ap.take((size_t)nb * 4);
+    const size_t o_el = ap.take((size_t)slots * 4), o_ek = ap.take((size_t)slots * 4), o_eo = ap.take((size_t)slots * 4);
+    const size_t o_out = ap.take(bound + 64);
+    u8* A = nullptr;
+    hipError_t e = hipMalloc((void**)&A, ap.total);
+    if (e != hipSuccess) return fail(ctx, PQD_E_NOMEM, "hipMalloc of the encode arena failed", e);
+    struct Free { u8* p; ~Free() { (void)hipFree(p); } } fr{A};
+    HIP_TRY(ctx, hipMemsetAsync(A + o_ent, 0xFF, (size_t)n_tiles * 8 + 1, st));
+    HIP_TRY(ctx, hipMemsetAsync(A + o_ext, 0, ((size_t)n_tiles + 1) * 4, st));
+    if (src_len) HIP_TRY(ctx, hipMemcpyAsync(A + o_src, src_host, src_len, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_pg, P.data(), n * sizeof(EncPage), hipMemcpyHostToDevice, st));
+    if (nb) HIP_TRY(ctx, hipMemcpyAsync(A + o_blk, B.data(), (size_t)nb * sizeof(EncBlock), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_tp, tile_prefix.data(), ((size_t)nb + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_ep, elem_prefix.data(), ((size_t)nb + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_cp, chunk_prefix.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
+    EncArgs a;
+    a.blocks = (EncBlock*)(A + o_blk); a.tile_prefix = (u32*)(A + o_tp); a.elem_prefix = (u32*)(A + o_ep);
+    a.n_blocks = nb; a.n_tiles = n_tiles; a.elem_slots = slots;
+    a.lead = (u32*)(A + o_lead); a.ext = (u32*)(A + o_ext); a.exits = A + o_exits; a.entries = A + o_ent;
+    a.n_elems = (u32*)(A + o_ne); a.out_len = (u32*)(A + o_ol);
+    a.elems = (u32*)(A + o_el); a.elem_k = (u32*)(A + o_ek); a.elem_off = (u32*)(A + o_eo);
+    HIP_TRY(ctx, launch_rle_encode_layout(st, A + o_src, a));
+    HIP_TRY(ctx, launch_encode_pages(st, A + o_src, (EncPage*)(A + o_pg), (u32*)(A + o_cp), (u32)n, chunk_prefix.back(),
+                                     (EncBlock*)(A + o_blk), (u32*)(A + o_ol), A + o_out));
+    HIP_TRY(ctx, launch_rle_encode_write(st, A + o_src, a));
+    HIP_TRY(ctx, hipMemcpyAsync(P.data(), A + o_pg, n * sizeof(EncPage), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const u64 total = P[n - 1].payload_off + P[n - 1].rep_bytes + P[n - 1].def_bytes + P[n - 1].val_bytes;
+    *out_len = (int64_t)total;
+    if (total > bound) return fail(ctx, PQD_E_CORRUPT, "encoder overran its bound");
+    for (size_t i = 0; i < n; i++) {
+        pqd_enc_result& r = results[i];
+        memset(&r, 0, sizeof r);
+        r.payload_off = (int64_t)P[i].payload_off;
+        r.payload_len = (int64_t)(P[i].rep_bytes + P[i].def_bytes + P[i].val_bytes);
+        r.rep_bytes = (int32_t)P[i].rep_bytes;
+        r.def_bytes = (int32_t)P[i].def_bytes;
+        r.null_count = pages[i].n_levels - pages[i].n_values;
+        if (P[i].width && !(pages[i].max_def > 0 && pages[i].n_values == 0)) {  // optional stats: nil while nonNils == 0
+            r.minmax_len = (int32_t)P[i].width;
+            memcpy(r.min, &P[i].min_bits, 8);
+            memcpy(r.max, &P[i].max_bits, 8);
+        }
+    }
+    if (total > out_cap) return fail(ctx, PQD_E_ARG, "destination too small");
+    if (total) {
+        if (!out_host) return PQD_E_ARG;
+        HIP_TRY(ctx, hipMemcpyAsync(out_host, A + o_out, total, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    return PQD_OK;
+}
+
 }  // extern "C"

@@ -170,5 +170,24 @@ struct EncArgs {
     u32 *elems, *elem_k, *elem_off;  // elem_slots each
 };
 hipError_t launch_rle_encode(hipStream_t st, const u8* src, const EncArgs& a);
+hipError_t launch_rle_encode_layout(hipStream_t st, const u8* src, const EncArgs& a);
+hipError_t launch_rle_encode_write(hipStream_t st, const u8* src, const EncArgs& a);
+constexpr u32 ENC_VALUE_CHUNK = 65536;  // value bytes (strings: 16 bytes counted per string) per workgroup of k_encp_values
+// one page to encode: [rep levels][def levels][PLAIN values]
+struct EncPage {
+    u64 values_off;   // dense LE values / one byte per bool / the chars of the strings
+    u64 offsets_off;  // strings: int32[n_values + 1], 4-byte aligned
+    u64 n_values;
+    u32 width;        // 4 / 8 for fixed-width types, else 0
+    int phys_type;
+    u32 stats_kind;   // 0 signed, 1 unsigned, 2 floating point
+    u32 rep_block, def_block;  // indices into the level block table, 0xFFFFFFFF = none
+    // filled on the device
+    u32 rep_bytes, def_bytes, pad;
+    u64 val_bytes, payload_off;
+    u64 min_bits, max_bits;
+};
+hipError_t launch_encode_pages(hipStream_t st, const u8* src, EncPage* pages, const u32* chunk_prefix, u32 n_pages, u32 n_chunks,
+                               EncBlock* blocks, const u32* out_len, u8* out_base);
 
 }  // namespace pqd

@@ -26,6 +26,7 @@ namespace pqd {
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_e __attribute__((aligned(1)));
 
 // End (exclusive) of the equal run that position p of the tile belongs to, from the tile's change masks:
 // bit k of s_mask[l] is set when v[tb + 32 l + k] != v[tb + 32 l + k + 1] (the last value of the block
@@ -326,10 +327,166 @@ __global__ __launch_bounds__(256) void k_enc_write(const u8* __restrict__ src, c
     }
 }
 
+// =====================================================================================
+// Page payloads (OptionalField.DoWrite / RequiredField.DoWrite, fields.go:95-111, 232-271): repetition
+// levels, definition levels, then the PLAIN values, back to back.
+//   k_encp_place   sizes of the three parts of every page -> payload offsets (scan over the pages), and the
+//                  destinations of the level blocks
+//   k_encp_values  PLAIN values: fixed width = the dense little-endian values as they are
+//                  (template_required.go:37-49, template_optional.go:96-114: binary.Write), bools 8 per
+//                  byte LSB first (template_bool.go), strings int32 length + bytes (template_string.go:62-78)
+//   k_encp_stats   min / max of the page's values the way the generated stats types keep them: min starts at
+//                  the type's maximum, max starts at ZERO (template_required.go:77-96, template_optional.go:
+//                  79-113), comparisons in the Go type (signed, unsigned, float)
+// =====================================================================================
+__global__ __launch_bounds__(1024) void k_encp_place(EncPage* __restrict__ pages, u32 n_pages, EncBlock* __restrict__ blocks,
+                                                     const u32* __restrict__ out_len, const u8* __restrict__ src,
+                                                     u8* __restrict__ out_base) {
+    __shared__ u64 s_sum[16];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 per = (n_pages + 1023) / 1024;
+    const u32 a = tid * per < n_pages ? tid * per : n_pages, b = a + per < n_pages ? a + per : n_pages;
+    u64 mine = 0;
+    for (u32 i = a; i < b; i++) {
+        EncPage P = pages[i];
+        P.rep_bytes = P.rep_block != 0xFFFFFFFFu ? out_len[P.rep_block] + 4 : 0;
+        P.def_bytes = P.def_block != 0xFFFFFFFFu ? out_len[P.def_block] + 4 : 0;
+        u64 vb;
+        if (P.width) vb = P.n_values * P.width;
+        else if (P.phys_type == PT_BOOLEAN) vb = (P.n_values + 7) / 8;
+        else {
+            const int* offs = (const int*)(src + P.offsets_off);
+            vb = 4 * P.n_values + (u64)(u32)(offs[P.n_values] - offs[0]);
+        }
+        P.val_bytes = vb;
+        pages[i].rep_bytes = P.rep_bytes; pages[i].def_bytes = P.def_bytes; pages[i].val_bytes = vb;
+        mine += (u64)P.rep_bytes + P.def_bytes + vb;
+    }
+    u64 incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 t = __shfl_up(incl, d);
+        if (lane >= (u32)d) incl += t;
+    }
+    if (lane == 63) s_sum[wv] = incl;
+    __syncthreads();
+    u64 run = incl - mine;
+    for (u32 q = 0; q < wv; q++) run += s_sum[q];
+    for (u32 i = a; i < b; i++) {
+        EncPage P = pages[i];
+        pages[i].payload_off = run;
+        if (P.rep_block != 0xFFFFFFFFu) blocks[P.rep_block].out = out_base + run;
+        if (P.def_block != 0xFFFFFFFFu) blocks[P.def_block].out = out_base + run + P.rep_bytes;
+        run += (u64)P.rep_bytes + P.def_bytes + P.val_bytes;
+    }
+}
+
+constexpr u32 ENP_CHUNK = ENC_VALUE_CHUNK;
+__global__ __launch_bounds__(256) void k_encp_values(const EncPage* __restrict__ pages, const u32* __restrict__ chunk_prefix,
+                                                     u32 n_pages, const u8* __restrict__ src, u8* __restrict__ out_base) {
+    const u32 blk = blockIdx.x, tid = threadIdx.x;
+    u32 lo = 0, hi = n_pages;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (chunk_prefix[mid] <= blk) lo = mid; else hi = mid; }
+    const EncPage P = pages[lo];
+    const u64 c0 = (u64)(blk - chunk_prefix[lo]) * ENP_CHUNK;
+    u8* dst = out_base + P.payload_off + P.rep_bytes + P.def_bytes;
+    if (P.width) {
+        const u64 n = P.n_values * P.width;
+        const u8* s = src + P.values_off;
+        const u64 c1 = c0 + ENP_CHUNK < n ? c0 + ENP_CHUNK : n;
+        for (u64 i = c0 + tid * 16; i < c1; i += 256 * 16) {
+            if (i + 16 <= c1) *(u32x4_e*)(dst + i) = *(const u32x4_e*)(s + i);
+            else for (u64 k = i; k < c1; k++) dst[k] = s[k];
+        }
+    } else if (P.phys_type == PT_BOOLEAN) {
+        // the chunk counts output bytes; 8 one-byte bools each
+        const u64 nb = (P.n_values + 7) / 8;
+        const u8* s = src + P.values_off;
+        const u64 c1 = c0 + ENP_CHUNK < nb ? c0 + ENP_CHUNK : nb;
+        for (u64 i = c0 + tid; i < c1; i += 256) {
+            u32 x = 0;
+            for (u32 j = 0; j < 8 && i * 8 + j < P.n_values; j++) x |= (u32)(s[i * 8 + j] != 0) << j;
+            dst[i] = (u8)x;
+        }
+    } else {
+        // the chunk counts strings here: ENP_CHUNK / 16 of them per workgroup, one thread per string
+        const int* offs = (const int*)(src + P.offsets_off);
+        const u8* chars = src + P.values_off;
+        const u64 per = ENP_CHUNK / 16, s0 = (u64)(blk - chunk_prefix[lo]) * per;
+        const u64 s1 = s0 + per < P.n_values ? s0 + per : P.n_values;
+        const int base = offs[0];
+        for (u64 i = s0 + tid; i < s1; i += 256) {
+            const u32 a = (u32)(offs[i] - base), len = (u32)(offs[i + 1] - offs[i]);
+            u8* d = dst + 4 * i + a;
+            d[0] = (u8)len; d[1] = (u8)(len >> 8); d[2] = (u8)(len >> 16); d[3] = (u8)(len >> 24);
+            const u8* c = chars + offs[i];
+            for (u32 k = 0; k < len; k++) d[4 + k] = c[k];
+        }
+    }
+}
+
+template <typename T>
+static __device__ void stats_reduce(const EncPage& P, const u8* src, EncPage* out) {
+    __shared__ unsigned long long s_min[4], s_max[4];
+    const T* v = (const T*)(src + P.values_off);
+    T mn, mx = (T)0;
+    if (sizeof(T) == 4) { const u32 b = P.stats_kind == 2 ? 0x7F7FFFFFu : P.stats_kind == 1 ? 0xFFFFFFFFu : 0x7FFFFFFFu; memcpy(&mn, &b, 4); }
+    else { const u64 b = P.stats_kind == 2 ? 0x7FEFFFFFFFFFFFFFull : P.stats_kind == 1 ? ~0ull : 0x7FFFFFFFFFFFFFFFull; memcpy(&mn, &b, 8); }
+    for (u64 i = threadIdx.x; i < P.n_values; i += 256) {
+        const T x = v[i];
+        if (x < mn) mn = x;
+        if (x > mx) mx = x;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        T a, b;
+        if (sizeof(T) == 4) {
+            u32 t, u; memcpy(&t, &mn, 4); memcpy(&u, &mx, 4);
+            t = __shfl_down(t, d); u = __shfl_down(u, d);
+            memcpy(&a, &t, 4); memcpy(&b, &u, 4);
+        } else {
+            u64 t, u; memcpy(&t, &mn, 8); memcpy(&u, &mx, 8);
+            t = __shfl_down(t, d); u = __shfl_down(u, d);
+            memcpy(&a, &t, 8); memcpy(&b, &u, 8);
+        }
+        if (a < mn) mn = a;
+        if (b > mx) mx = b;
+    }
+    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { unsigned long long t = 0, u = 0; memcpy(&t, &mn, sizeof(T)); memcpy(&u, &mx, sizeof(T)); s_min[wv] = t; s_max[wv] = u; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (u32 q = 1; q < 4; q++) {
+            T a, b;
+            memcpy(&a, &s_min[q], sizeof(T)); memcpy(&b, &s_max[q], sizeof(T));
+            if (a < mn) mn = a;
+            if (b > mx) mx = b;
+        }
+        u64 t = 0, u = 0;
+        memcpy(&t, &mn, sizeof(T)); memcpy(&u, &mx, sizeof(T));
+        out->min_bits = t; out->max_bits = u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_encp_stats(EncPage* __restrict__ pages, const u8* __restrict__ src) {
+    const EncPage P = pages[blockIdx.x];
+    EncPage* out = pages + blockIdx.x;
+    if (!P.width) return;
+    // stats_kind: 0 signed, 1 unsigned, 2 floating point
+    if (P.width == 4) {
+        if (P.stats_kind == 0) stats_reduce<int>(P, src, out);
+        else if (P.stats_kind == 1) stats_reduce<u32>(P, src, out);
+        else stats_reduce<float>(P, src, out);
+    } else {
+        if (P.stats_kind == 0) stats_reduce<long long>(P, src, out);
+        else if (P.stats_kind == 1) stats_reduce<u64>(P, src, out);
+        else stats_reduce<double>(P, src, out);
+    }
+}
+
 // ---- launchers -------------------------------------------------------------------------------
 #define ENC_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
-hipError_t launch_rle_encode(hipStream_t st, const u8* src, const EncArgs& a) {
+// layout: everything up to the size of every block (out_len) and the byte offset of every element
+hipError_t launch_rle_encode_layout(hipStream_t st, const u8* src, const EncArgs& a) {
     if (a.n_blocks == 0) return hipSuccess;
     if (a.n_tiles) {
         hipLaunchKernelGGL(k_enc_lead, dim3(a.n_tiles), dim3(64), 0, st, src, a.blocks, a.tile_prefix, a.n_blocks, a.lead);
@@ -350,9 +507,32 @@ hipError_t launch_rle_encode(hipStream_t st, const u8* src, const EncArgs& a) {
     }
     hipLaunchKernelGGL(k_enc_layout, dim3(a.n_blocks), dim3(1024), 0, st, a.blocks, a.n_elems, a.elems, a.elem_k, a.elem_off, a.out_len);
     ENC_CHECK();
+    return hipSuccess;
+}
+// write: the bytes, to EncBlock.out of every block
+hipError_t launch_rle_encode_write(hipStream_t st, const u8* src, const EncArgs& a) {
+    if (a.n_blocks == 0) return hipSuccess;
     const u32 slots = a.elem_slots ? a.elem_slots : 1;
     hipLaunchKernelGGL(k_enc_write, dim3((slots + 255) / 256), dim3(256), 0, st, src, a.blocks, a.elem_prefix, a.n_blocks, a.n_elems,
                        a.elems, a.elem_k, a.elem_off, a.out_len);
+    ENC_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_rle_encode(hipStream_t st, const u8* src, const EncArgs& a) {
+    hipError_t e = launch_rle_encode_layout(st, src, a);
+    return e != hipSuccess ? e : launch_rle_encode_write(st, src, a);
+}
+
+hipError_t launch_encode_pages(hipStream_t st, const u8* src, EncPage* pages, const u32* chunk_prefix, u32 n_pages, u32 n_chunks,
+                               EncBlock* blocks, const u32* out_len, u8* out_base) {
+    if (n_pages == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_encp_place, dim3(1), dim3(1024), 0, st, pages, n_pages, blocks, out_len, src, out_base);
+    ENC_CHECK();
+    if (n_chunks) {
+        hipLaunchKernelGGL(k_encp_values, dim3(n_chunks), dim3(256), 0, st, pages, chunk_prefix, n_pages, src, out_base);
+        ENC_CHECK();
+    }
+    hipLaunchKernelGGL(k_encp_stats, dim3(n_pages), dim3(256), 0, st, pages, src);
     ENC_CHECK();
     return hipSuccess;
 }

@@ -183,3 +183,69 @@ def snappy_compress(data):
     n = N.synth.pqw_snappy_compress(src, len(data), out, cap)
     assert n >= 0
     return bytes(out[:n])
+
+
+def encode_pages(ctx, pages):
+    """pqd_encode_pages: page payloads of the write path on the device.
+
+    pages: list of dicts with phys_type, max_def, max_rep, values (numpy array; for strings a
+    (chars uint8 array, offsets int32 array) pair), optional defs / reps (uint8) and is_unsigned.
+    Returns a list of (payload bytes, result) where result has rep_bytes, def_bytes, null_count, min, max
+    (bytes or None)."""
+    import numpy as np
+    parts, pos = [], 0
+
+    def put(arr, align):
+        nonlocal pos
+        pad = (-pos) % align
+        if pad:
+            parts.append(b"\0" * pad)
+            pos += pad
+        off = pos
+        b = np.ascontiguousarray(arr).tobytes()
+        parts.append(b)
+        pos += len(b)
+        return off
+
+    descs = (N.EncPage * max(len(pages), 1))()
+    for d, pg in zip(descs, pages):
+        d.phys_type, d.max_def, d.max_rep = pg["phys_type"], pg["max_def"], pg["max_rep"]
+        d.is_unsigned = 1 if pg.get("is_unsigned") else 0
+        d.defs_off = d.reps_off = d.offsets_off = -1
+        if pg["phys_type"] == N.BYTE_ARRAY:
+            chars, offs = pg["values"]
+            offs = np.ascontiguousarray(offs, np.int32)
+            d.n_values = offs.size - 1
+            d.values_off = put(np.ascontiguousarray(chars, np.uint8), 8)
+            d.offsets_off = put(offs, 8)
+        else:
+            v = np.ascontiguousarray(pg["values"])
+            if pg["phys_type"] == N.BOOLEAN:
+                v = v.astype(np.uint8)
+            d.n_values = v.size
+            d.values_off = put(v, 8)
+        if pg["max_def"] > 0:
+            defs = np.ascontiguousarray(pg["defs"], np.uint8)
+            d.n_levels = defs.size
+            d.defs_off = put(defs, 8)
+            if pg["max_rep"] > 0:
+                d.reps_off = put(np.ascontiguousarray(pg["reps"], np.uint8), 8)
+        else:
+            d.n_levels = d.n_values
+    src = b"".join(parts) or b"\0"
+    host = np.frombuffer(src, np.uint8)
+    cap = 64 + len(src) * 2 + 64 * len(pages)
+    out = np.zeros(cap, np.uint8)
+    res = (N.EncResult * max(len(pages), 1))()
+    n = C.c_int64()
+    rc = N.decode.pqd_encode_pages(ctx.handle, descs, len(pages), host.ctypes.data, len(src), out.ctypes.data, cap, res, C.byref(n))
+    if rc != 0:
+        m = N.decode.pqd_last_error(ctx.handle)
+        raise N.PqdError(rc, m.decode() if m else "")
+    ret = []
+    for r in res[:len(pages)]:
+        info = {"rep_bytes": r.rep_bytes, "def_bytes": r.def_bytes, "null_count": r.null_count,
+                "min": bytes(r.min[:r.minmax_len]) if r.minmax_len else None,
+                "max": bytes(r.max[:r.minmax_len]) if r.minmax_len else None}
+        ret.append((out[r.payload_off:r.payload_off + r.payload_len].tobytes(), info))
+    return ret

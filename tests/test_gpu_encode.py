@@ -85,3 +85,118 @@ def test_wide_levels_round_trip(ctx, width):
         enc = R.rle_encode(ctx, width, lv)
         dec, total = R.rle_decode(ctx, width, enc, n + 8)
         assert total >= n and np.array_equal(dec[:n], lv) and not dec[n:total].any()
+
+
+# ---------------------------------------------------------------- page payloads
+import helpers as H  # noqa: E402
+from parquet_amd import _native as N  # noqa: E402
+from parquet_amd.writer import Column, ParquetWriter, encode_pages  # noqa: E402
+
+
+def _file_payloads(buf):
+    """The page payloads of an uncompressed file, in file order."""
+    pf = R.ParquetFile(buf)
+    out = []
+    for i in range(pf.num_pages):
+        h = pf.page_header(i)
+        a = h["pos"] + h["header_len"]
+        out.append(bytes(buf[a:a + h["uncompressed_page_size"]]))
+    return out
+
+
+def _ref_minmax(values, np_type):
+    """min starts at the type's maximum, max starts at zero (template_required.go:77-96)."""
+    v = np.asarray(values, np_type)
+    if np.issubdtype(np_type, np.floating):
+        mn, mx = np.finfo(np_type).max, np_type(0)
+    else:
+        mn, mx = np.iinfo(np_type).max, np_type(0)
+    for x in v:  # NaN never wins a Go comparison
+        if x < mn:
+            mn = x
+        if x > mx:
+            mx = x
+    return np.array([mn], np_type).tobytes(), np.array([mx], np_type).tobytes()
+
+
+def test_page_payloads_match_the_writer(ctx):
+    """The same pages through the synthetic writer (whose level blocks are pinned to the reference encoder
+    and whose PLAIN layout the oracle reads back) and through the device encoder."""
+    rng = np.random.default_rng(70)
+    cols = [Column("a", N.INT32, [0]), Column("b", N.INT64, [1]), Column("f", N.FLOAT, [1]), Column("d", N.DOUBLE, [0]),
+            Column("s", N.BYTE_ARRAY, [1]), Column("t", N.BYTE_ARRAY, [0]), Column("k", N.BOOLEAN, [1]),
+            Column("r.x", N.INT32, [2, 1]), Column("r.s", N.BYTE_ARRAY, [2, 0])]
+    w = ParquetWriter(cols, stats=False)
+    w.begin_row_group()
+    pages = []
+    for ci, c in enumerate(cols):
+        for nr in (1, 7, 1000, 5000, 20011):
+            if c.max_def > 0:
+                defs, reps, nv = H.gen_levels(c.types, nr, rng, 0.3)
+            else:
+                defs, reps, nv = None, None, nr
+            pg = {"phys_type": c.phys_type, "max_def": c.max_def, "max_rep": c.max_rep, "defs": defs, "reps": reps}
+            if c.phys_type == N.BYTE_ARRAY:
+                chars, offs = H.random_strings(nv, rng, 0, 24, (0, 256))
+                w.write_page(ci, chars, defs=defs, reps=reps, offsets=offs)
+                pg["values"] = (chars, offs)
+            else:
+                v = H.random_values(c.phys_type, nv, rng)
+                w.write_page(ci, v, defs=defs, reps=reps)
+                pg["values"] = v
+            pages.append(pg)
+    w.end_row_group(1)
+    buf = w.finish()
+    w.close()
+    want = _file_payloads(buf)
+    got = encode_pages(ctx, pages)
+    assert len(want) == len(got)
+    for i, ((payload, info), pg) in enumerate(zip(got, pages)):
+        assert payload == want[i], (i, pg["phys_type"], len(payload), len(want[i]))
+        n_levels = len(pg["defs"]) if pg["defs"] is not None else 0
+        if pg["max_def"] > 0:
+            nv = len(pg["values"][1]) - 1 if pg["phys_type"] == N.BYTE_ARRAY else len(pg["values"])
+            assert info["null_count"] == n_levels - nv
+        np_type = {N.INT32: np.int32, N.INT64: np.int64, N.FLOAT: np.float32, N.DOUBLE: np.float64}.get(pg["phys_type"])
+        if np_type is None or (pg["max_def"] > 0 and len(pg["values"]) == 0):
+            assert info["min"] is None and info["max"] is None
+        else:
+            assert (info["min"], info["max"]) == _ref_minmax(pg["values"], np_type), i
+
+
+def test_page_payloads_round_trip_through_the_oracle(ctx):
+    """Device-encoded pages, framed by the writer as raw pages, read back by the oracle reader."""
+    rng = np.random.default_rng(71)
+    cols = [Column("a", N.INT32, [1]), Column("s", N.BYTE_ARRAY, [1]), Column("r.x", N.INT64, [2, 1])]
+    pages, per_col = [], []
+    for c in cols:
+        mine = []
+        for nr in (3000, 4096, 9001):
+            defs, reps, nv = H.gen_levels(c.types, nr, rng, 0.2)
+            pg = {"phys_type": c.phys_type, "max_def": c.max_def, "max_rep": c.max_rep, "defs": defs, "reps": reps}
+            pg["values"] = H.random_strings(nv, rng, 0, 16, (97, 123)) if c.phys_type == N.BYTE_ARRAY else H.random_values(c.phys_type, nv, rng)
+            mine.append(len(pages))
+            pages.append(pg)
+        per_col.append(mine)
+    enc = encode_pages(ctx, pages)
+    w = ParquetWriter(cols, stats=False)
+    w.begin_row_group()
+    for ci, mine in enumerate(per_col):
+        for i in mine:
+            w.write_raw_page(ci, enc[i][0], len(pages[i]["defs"]))
+    w.end_row_group(1)
+    buf = w.finish()
+    w.close()
+    o = H.oracle_file(buf)
+    for ci, (c, mine) in enumerate(zip(cols, per_col)):
+        ch = o[(0, c.path)]
+        assert ch.error == 0
+        assert np.array_equal(ch.defs, np.concatenate([pages[i]["defs"] for i in mine]))
+        if c.max_rep:
+            assert np.array_equal(ch.reps, np.concatenate([pages[i]["reps"] for i in mine]))
+        if c.phys_type == N.BYTE_ARRAY:
+            assert ch.values.tobytes() == b"".join(np.asarray(pages[i]["values"][0]).tobytes() for i in mine)
+        else:
+            assert ch.values.tobytes() == b"".join(np.asarray(pages[i]["values"]).tobytes() for i in mine)
+    # and the decoder reads them too
+    H.check_file(buf, ctx)
