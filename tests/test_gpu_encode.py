@@ -200,3 +200,31 @@ def test_page_payloads_round_trip_through_the_oracle(ctx):
             assert ch.values.tobytes() == b"".join(np.asarray(pages[i]["values"]).tobytes() for i in mine)
     # and the decoder reads them too
     H.check_file(buf, ctx)
+
+
+def test_page_payload_edge_cases(ctx):
+    pages = [
+        {"phys_type": N.INT32, "max_def": 1, "max_rep": 0, "defs": np.zeros(100, np.uint8), "reps": None,
+         "values": np.zeros(0, np.int32)},                                             # all null
+        {"phys_type": N.INT32, "max_def": 0, "max_rep": 0, "defs": None, "reps": None, "values": np.zeros(0, np.int32)},  # empty
+        {"phys_type": N.INT32, "max_def": 0, "max_rep": 0, "defs": None, "reps": None,
+         "values": np.array([-5, -1, -7], np.int32)},                                  # all negative: max stays 0
+        {"phys_type": N.INT32, "max_def": 0, "max_rep": 0, "defs": None, "reps": None, "is_unsigned": True,
+         "values": np.array([0xFFFFFFF0, 3, 7], np.uint32).view(np.int32)},            # UINT_32 compares unsigned
+        {"phys_type": N.INT64, "max_def": 0, "max_rep": 0, "defs": None, "reps": None, "is_unsigned": True,
+         "values": np.array([2**63 + 5, 9], np.uint64).view(np.int64)},
+        {"phys_type": N.BYTE_ARRAY, "max_def": 0, "max_rep": 0, "defs": None, "reps": None,
+         "values": (np.zeros(0, np.uint8), np.zeros(4, np.int32))},                    # three empty strings
+        {"phys_type": N.BOOLEAN, "max_def": 0, "max_rep": 0, "defs": None, "reps": None,
+         "values": np.array([1, 0, 1, 1, 0, 0, 0, 0, 1], np.uint8)},                   # 9 bools: 2 bytes
+    ]
+    got = encode_pages(ctx, pages)
+    assert got[0][0] == bytes(O.rle_encode(1, np.zeros(100, np.uint8))) and got[0][1]["null_count"] == 100
+    assert got[0][1]["min"] is None and got[0][1]["def_bytes"] == len(got[0][0])
+    assert got[1][0] == b"" and got[1][1]["min"] == np.array([2**31 - 1], np.int32).tobytes() and got[1][1]["max"] == bytes(4)
+    assert got[2][0] == np.array([-5, -1, -7], np.int32).tobytes()
+    assert got[2][1]["min"] == np.array([-7], np.int32).tobytes() and got[2][1]["max"] == bytes(4)
+    assert got[3][1]["min"] == np.array([3], np.uint32).tobytes() and got[3][1]["max"] == np.array([0xFFFFFFF0], np.uint32).tobytes()
+    assert got[4][1]["min"] == np.array([9], np.uint64).tobytes() and got[4][1]["max"] == np.array([2**63 + 5], np.uint64).tobytes()
+    assert got[5][0] == bytes(12) and got[5][1]["min"] is None
+    assert got[6][0] == bytes([0b00001101, 0b00000001])
