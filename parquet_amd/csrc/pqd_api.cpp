@@ -1213,6 +1213,7 @@ int pqd_encode_pages(pqd_ctx* ctx, const pqd_enc_page* pages, size_t n, const vo
     const size_t o_ne = ap.take((size_t)nb * 4), o_ol = ap.take((size_t)nb * 4);
     const size_t o_el = ap.take((size_t)slots * 4), o_ek = ap.take((size_t)slots * 4), o_eo = ap.take((size_t)slots * 4);
     const size_t o_out = ap.take(bound + 64);
+    const size_t o_sp = ap.take((size_t)chunk_prefix.back() * 16);
     u8* A = nullptr;
     hipError_t e = hipMalloc((void**)&A, ap.total);
     if (e != hipSuccess) return fail(ctx, PQD_E_NOMEM, "hipMalloc of the encode arena failed", e);
@@ -1233,7 +1234,7 @@ int pqd_encode_pages(pqd_ctx* ctx, const pqd_enc_page* pages, size_t n, const vo
     a.elems = (u32*)(A + o_el); a.elem_k = (u32*)(A + o_ek); a.elem_off = (u32*)(A + o_eo);
     HIP_TRY(ctx, launch_rle_encode_layout(st, A + o_src, a));
     HIP_TRY(ctx, launch_encode_pages(st, A + o_src, (EncPage*)(A + o_pg), (u32*)(A + o_cp), (u32)n, chunk_prefix.back(),
-                                     (EncBlock*)(A + o_blk), (u32*)(A + o_ol), A + o_out));
+                                     (EncBlock*)(A + o_blk), (u32*)(A + o_ol), A + o_out, (u64*)(A + o_sp)));
     HIP_TRY(ctx, launch_rle_encode_write(st, A + o_src, a));
     HIP_TRY(ctx, hipMemcpyAsync(P.data(), A + o_pg, n * sizeof(EncPage), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -188,6 +188,6 @@ struct EncPage {
     u64 min_bits, max_bits;
 };
 hipError_t launch_encode_pages(hipStream_t st, const u8* src, EncPage* pages, const u32* chunk_prefix, u32 n_pages, u32 n_chunks,
-                               EncBlock* blocks, const u32* out_len, u8* out_base);
+                               EncBlock* blocks, const u32* out_len, u8* out_base, u64* stats_partial);
 
 }  // namespace pqd

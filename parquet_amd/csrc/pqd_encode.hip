@@ -107,18 +107,37 @@ __global__ __launch_bounds__(64) void k_enc_lead(const u8* __restrict__ src, con
 }
 
 // ext[t] = how far the equal run that reaches the end of tile t - 1 goes on from the start of tile t,
-// across as many whole tiles as it covers
-__global__ void k_enc_ext(const EncBlock* __restrict__ blocks, const u32* __restrict__ tile_prefix, u32 n_blocks,
-                          const u32* __restrict__ lead, u32* __restrict__ ext) {
-    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_blocks) return;
-    const u32 t0 = tile_prefix[b], t1 = tile_prefix[b + 1];
-    u32 carry = 0;
-    for (u32 t = t1; t-- > t0;) {
-        const u32 l = lead[t];
-        const u32 e = l == EN_T ? EN_T + carry : l;  // a tile covered entirely hands over to the next one
-        ext[t] = e;
-        carry = e;
+// across as many whole tiles as it covers: with nf = the first tile at or after t that the run does not
+// cover entirely, ext[t] = (nf - t) * EN_T + lead[nf].  nf is a reverse min-scan over the block's tiles;
+// one workgroup per block, batches of 1024 tiles from the end with a carry.
+__global__ __launch_bounds__(1024) void k_enc_ext(const EncBlock* __restrict__ blocks, const u32* __restrict__ tile_prefix, u32 n_blocks,
+                                                  const u32* __restrict__ lead, u32* __restrict__ ext) {
+    __shared__ u32 s_w[16];
+    const u32 b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 t0 = tile_prefix[b], nt = tile_prefix[b + 1] - t0;
+    const u32 NONE = 0xFFFFFFFFu;
+    u32 carry = NONE;  // first not-covered tile after the current batch
+    for (u32 hi = nt; hi > 0; hi = hi > 1024 ? hi - 1024 : 0) {
+        const u32 lo = hi > 1024 ? hi - 1024 : 0;
+        const u32 t = lo + tid;
+        const bool valid = t < hi;
+        const u32 l = valid ? lead[t0 + t] : 0;
+        u32 nf = valid && l < EN_T ? t : NONE;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 o = __shfl_down(nf, d);
+            if (lane + d < 64 && o < nf) nf = o;
+        }
+        if (lane == 0) s_w[wv] = nf;
+        __syncthreads();
+        u32 after = carry, batch_min = carry;
+        for (u32 q = 0; q < 16; q++) {
+            if (q > wv && s_w[q] < after) after = s_w[q];
+            if (s_w[q] < batch_min) batch_min = s_w[q];
+        }
+        if (after < nf) nf = after;
+        if (valid) ext[t0 + t] = nf == NONE ? (nt - t) * EN_T : (nf - t) * EN_T + lead[t0 + nf];
+        carry = batch_min;
+        __syncthreads();
     }
 }
 
@@ -165,20 +184,30 @@ __global__ __launch_bounds__(64) void k_enc_exits(const u8* __restrict__ src, co
     exits[(u64)tile * EN_E + lane] = x;
 }
 
-// True entry (block position, element index) of every tile; total elements of the block.
-__global__ void k_enc_hop(const EncBlock* __restrict__ blocks, const u32* __restrict__ tile_prefix, u32 n_blocks,
-                          const u32* __restrict__ lead, const EncExit* __restrict__ exits, EncExit* __restrict__ entries,
-                          u32* __restrict__ n_elems) {
-    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_blocks) return;
-    const u32 n = blocks[b].n, t0 = tile_prefix[b];
+// True entry (block position, element index) of every tile; total elements of the block.  One workgroup
+// per block: the block's exit table is staged in LDS when it fits (a 1M-level page has 489 tiles), so that
+// the one thread that follows the chain pays LDS latency per tile instead of a global load.
+constexpr u32 EN_HOP_LDS_TILES = 800;
+__global__ __launch_bounds__(256) void k_enc_hop(const EncBlock* __restrict__ blocks, const u32* __restrict__ tile_prefix, u32 n_blocks,
+                                                 const u32* __restrict__ lead, const EncExit* __restrict__ exits,
+                                                 EncExit* __restrict__ entries, u32* __restrict__ n_elems) {
+    __shared__ EncExit s_ex[EN_HOP_LDS_TILES * EN_E];
+    const u32 b = blockIdx.x;
+    const u32 n = blocks[b].n, t0 = tile_prefix[b], nt = tile_prefix[b + 1] - t0;
+    const bool staged = nt <= EN_HOP_LDS_TILES;
+    if (staged) {
+        for (u32 i = threadIdx.x; i < nt * EN_E; i += 256) s_ex[i] = exits[(u64)t0 * EN_E + i];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
     u32 p = 0, cnt = 0;
     while (p < n) {
         const u32 t = p / EN_T, off = p - t * EN_T;
         EncExit e;
         e.pos = p; e.cnt = cnt;
         entries[t0 + t] = e;
-        const EncExit x = exits[(u64)(t0 + t) * EN_E + (off < 8 ? off : 8)];  // off >= 8 is the run end: entry 8
+        const u32 slot = t * EN_E + (off < 8 ? off : 8);  // off >= 8 is the run end: entry 8
+        const EncExit x = staged ? s_ex[slot] : exits[(u64)t0 * EN_E + slot];
         p = x.pos;
         cnt += x.cnt;
     }
@@ -424,18 +453,16 @@ __global__ __launch_bounds__(256) void k_encp_values(const EncPage* __restrict__
     }
 }
 
+// statistics in two steps: every 64 KiB chunk of a page's values reduces to a partial (min, max), then one
+// wave per page folds its partials.  Both start from the stats types' initial values (type maximum, zero).
 template <typename T>
-static __device__ void stats_reduce(const EncPage& P, const u8* src, EncPage* out) {
-    __shared__ unsigned long long s_min[4], s_max[4];
-    const T* v = (const T*)(src + P.values_off);
-    T mn, mx = (T)0;
-    if (sizeof(T) == 4) { const u32 b = P.stats_kind == 2 ? 0x7F7FFFFFu : P.stats_kind == 1 ? 0xFFFFFFFFu : 0x7FFFFFFFu; memcpy(&mn, &b, 4); }
-    else { const u64 b = P.stats_kind == 2 ? 0x7FEFFFFFFFFFFFFFull : P.stats_kind == 1 ? ~0ull : 0x7FFFFFFFFFFFFFFFull; memcpy(&mn, &b, 8); }
-    for (u64 i = threadIdx.x; i < P.n_values; i += 256) {
-        const T x = v[i];
-        if (x < mn) mn = x;
-        if (x > mx) mx = x;
-    }
+static __device__ __forceinline__ void stats_init(u32 kind, T& mn, T& mx) {
+    mx = (T)0;
+    if (sizeof(T) == 4) { const u32 b = kind == 2 ? 0x7F7FFFFFu : kind == 1 ? 0xFFFFFFFFu : 0x7FFFFFFFu; memcpy(&mn, &b, 4); }
+    else { const u64 b = kind == 2 ? 0x7FEFFFFFFFFFFFFFull : kind == 1 ? ~0ull : 0x7FFFFFFFFFFFFFFFull; memcpy(&mn, &b, 8); }
+}
+template <typename T>
+static __device__ __forceinline__ void stats_wave(T& mn, T& mx) {
     for (int d = 32; d > 0; d >>= 1) {
         T a, b;
         if (sizeof(T) == 4) {
@@ -450,6 +477,20 @@ static __device__ void stats_reduce(const EncPage& P, const u8* src, EncPage* ou
         if (a < mn) mn = a;
         if (b > mx) mx = b;
     }
+}
+template <typename T>
+static __device__ void stats_chunk(const EncPage& P, const u8* src, u64 c0, u64* part) {
+    __shared__ unsigned long long s_min[4], s_max[4];
+    const T* v = (const T*)(src + P.values_off);
+    const u64 i0 = c0 / sizeof(T), i1 = i0 + ENC_VALUE_CHUNK / sizeof(T) < P.n_values ? i0 + ENC_VALUE_CHUNK / sizeof(T) : P.n_values;
+    T mn, mx;
+    stats_init<T>(P.stats_kind, mn, mx);
+    for (u64 i = i0 + threadIdx.x; i < i1; i += 256) {
+        const T x = v[i];
+        if (x < mn) mn = x;
+        if (x > mx) mx = x;
+    }
+    stats_wave<T>(mn, mx);
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) { unsigned long long t = 0, u = 0; memcpy(&t, &mn, sizeof(T)); memcpy(&u, &mx, sizeof(T)); s_min[wv] = t; s_max[wv] = u; }
     __syncthreads();
@@ -462,24 +503,57 @@ static __device__ void stats_reduce(const EncPage& P, const u8* src, EncPage* ou
         }
         u64 t = 0, u = 0;
         memcpy(&t, &mn, sizeof(T)); memcpy(&u, &mx, sizeof(T));
+        part[0] = t; part[1] = u;
+    }
+}
+template <typename T>
+static __device__ void stats_fold(const EncPage& P, const u64* part, u32 n_part, EncPage* out) {
+    T mn, mx;
+    stats_init<T>(P.stats_kind, mn, mx);
+    for (u32 i = threadIdx.x; i < n_part; i += 64) {
+        T a, b;
+        memcpy(&a, &part[2 * i], sizeof(T)); memcpy(&b, &part[2 * i + 1], sizeof(T));
+        if (a < mn) mn = a;
+        if (b > mx) mx = b;
+    }
+    stats_wave<T>(mn, mx);
+    if (threadIdx.x == 0) {
+        u64 t = 0, u = 0;
+        memcpy(&t, &mn, sizeof(T)); memcpy(&u, &mx, sizeof(T));
         out->min_bits = t; out->max_bits = u;
     }
 }
 
-__global__ __launch_bounds__(256) void k_encp_stats(EncPage* __restrict__ pages, const u8* __restrict__ src) {
-    const EncPage P = pages[blockIdx.x];
-    EncPage* out = pages + blockIdx.x;
+#define STATS_DISPATCH(FN, ...)                                              \
+    do {                                                                      \
+        if (P.width == 4) {                                                   \
+            if (P.stats_kind == 0) FN<int>(__VA_ARGS__);                      \
+            else if (P.stats_kind == 1) FN<u32>(__VA_ARGS__);                 \
+            else FN<float>(__VA_ARGS__);                                      \
+        } else {                                                              \
+            if (P.stats_kind == 0) FN<long long>(__VA_ARGS__);                \
+            else if (P.stats_kind == 1) FN<u64>(__VA_ARGS__);                 \
+            else FN<double>(__VA_ARGS__);                                     \
+        }                                                                     \
+    } while (0)
+
+// stats_kind: 0 signed, 1 unsigned, 2 floating point
+__global__ __launch_bounds__(256) void k_encp_stats_chunks(const EncPage* __restrict__ pages, const u32* __restrict__ chunk_prefix,
+                                                           u32 n_pages, const u8* __restrict__ src, u64* __restrict__ partial) {
+    const u32 blk = blockIdx.x;
+    u32 lo = 0, hi = n_pages;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (chunk_prefix[mid] <= blk) lo = mid; else hi = mid; }
+    const EncPage P = pages[lo];
     if (!P.width) return;
-    // stats_kind: 0 signed, 1 unsigned, 2 floating point
-    if (P.width == 4) {
-        if (P.stats_kind == 0) stats_reduce<int>(P, src, out);
-        else if (P.stats_kind == 1) stats_reduce<u32>(P, src, out);
-        else stats_reduce<float>(P, src, out);
-    } else {
-        if (P.stats_kind == 0) stats_reduce<long long>(P, src, out);
-        else if (P.stats_kind == 1) stats_reduce<u64>(P, src, out);
-        else stats_reduce<double>(P, src, out);
-    }
+    const u64 c0 = (u64)(blk - chunk_prefix[lo]) * ENC_VALUE_CHUNK;
+    STATS_DISPATCH(stats_chunk, P, src, c0, partial + 2 * (u64)blk);
+}
+__global__ __launch_bounds__(64) void k_encp_stats_pages(EncPage* __restrict__ pages, const u32* __restrict__ chunk_prefix,
+                                                         const u64* __restrict__ partial) {
+    const EncPage P = pages[blockIdx.x];
+    if (!P.width) return;
+    const u32 c0 = chunk_prefix[blockIdx.x], c1 = chunk_prefix[blockIdx.x + 1];
+    STATS_DISPATCH(stats_fold, P, partial + 2 * (u64)c0, c1 - c0, pages + blockIdx.x);
 }
 
 // ---- launchers -------------------------------------------------------------------------------
@@ -491,13 +565,13 @@ hipError_t launch_rle_encode_layout(hipStream_t st, const u8* src, const EncArgs
     if (a.n_tiles) {
         hipLaunchKernelGGL(k_enc_lead, dim3(a.n_tiles), dim3(64), 0, st, src, a.blocks, a.tile_prefix, a.n_blocks, a.lead);
         ENC_CHECK();
-        hipLaunchKernelGGL(k_enc_ext, dim3((a.n_blocks + 63) / 64), dim3(64), 0, st, a.blocks, a.tile_prefix, a.n_blocks, a.lead, a.ext);
+        hipLaunchKernelGGL(k_enc_ext, dim3(a.n_blocks), dim3(1024), 0, st, a.blocks, a.tile_prefix, a.n_blocks, a.lead, a.ext);
         ENC_CHECK();
         hipLaunchKernelGGL(k_enc_exits, dim3(a.n_tiles), dim3(64), 0, st, src, a.blocks, a.tile_prefix, a.n_blocks, a.lead, a.ext,
                            (EncExit*)a.exits);
         ENC_CHECK();
     }
-    hipLaunchKernelGGL(k_enc_hop, dim3((a.n_blocks + 63) / 64), dim3(64), 0, st, a.blocks, a.tile_prefix, a.n_blocks, a.lead,
+    hipLaunchKernelGGL(k_enc_hop, dim3(a.n_blocks), dim3(256), 0, st, a.blocks, a.tile_prefix, a.n_blocks, a.lead,
                        (const EncExit*)a.exits, (EncExit*)a.entries, a.n_elems);
     ENC_CHECK();
     if (a.n_tiles) {
@@ -524,7 +598,7 @@ hipError_t launch_rle_encode(hipStream_t st, const u8* src, const EncArgs& a) {
 }
 
 hipError_t launch_encode_pages(hipStream_t st, const u8* src, EncPage* pages, const u32* chunk_prefix, u32 n_pages, u32 n_chunks,
-                               EncBlock* blocks, const u32* out_len, u8* out_base) {
+                               EncBlock* blocks, const u32* out_len, u8* out_base, u64* stats_partial) {
     if (n_pages == 0) return hipSuccess;
     hipLaunchKernelGGL(k_encp_place, dim3(1), dim3(1024), 0, st, pages, n_pages, blocks, out_len, src, out_base);
     ENC_CHECK();
@@ -532,7 +606,11 @@ hipError_t launch_encode_pages(hipStream_t st, const u8* src, EncPage* pages, co
         hipLaunchKernelGGL(k_encp_values, dim3(n_chunks), dim3(256), 0, st, pages, chunk_prefix, n_pages, src, out_base);
         ENC_CHECK();
     }
-    hipLaunchKernelGGL(k_encp_stats, dim3(n_pages), dim3(256), 0, st, pages, src);
+    if (n_chunks) {
+        hipLaunchKernelGGL(k_encp_stats_chunks, dim3(n_chunks), dim3(256), 0, st, pages, chunk_prefix, n_pages, src, stats_partial);
+        ENC_CHECK();
+    }
+    hipLaunchKernelGGL(k_encp_stats_pages, dim3(n_pages), dim3(64), 0, st, pages, chunk_prefix, stats_partial);
     ENC_CHECK();
     return hipSuccess;
 }

@@ -228,3 +228,16 @@ def test_page_payload_edge_cases(ctx):
     assert got[4][1]["min"] == np.array([9], np.uint64).tobytes() and got[4][1]["max"] == np.array([2**63 + 5], np.uint64).tobytes()
     assert got[5][0] == bytes(12) and got[5][1]["min"] is None
     assert got[6][0] == bytes([0b00001101, 0b00000001])
+
+
+def test_blocks_of_more_than_1024_tiles(ctx):
+    """The per-block scans work in batches of 1024 tiles / elements with carries."""
+    rng = np.random.default_rng(12)
+    n = 2048 * 1100 + 5
+    lv = rng.integers(0, 2, n).astype(np.uint8)
+    lv[2048 * 10 + 7:2048 * 1090 + 3] = 1      # one run over 1080 tiles
+    lv[2048 * 1095:2048 * 1097] = 0            # and one over exactly two
+    assert R.rle_encode(ctx, 1, lv) == bytes(O.rle_encode(1, lv))
+    lv2 = rng.integers(0, 4, n).astype(np.uint8)  # no long runs: ~275k bit-packed groups
+    assert R.rle_encode(ctx, 2, lv2) == bytes(O.rle_encode(2, lv2))
+    assert R.rle_encode(ctx, 1, np.ones(n, np.uint8)) == bytes(O.rle_encode(1, np.ones(n, np.uint8)))
