@@ -1085,9 +1085,11 @@ int pqd_rle_encode(pqd_ctx* ctx, int width, const void* levels_host, size_t n, v
     const size_t o_lead = ap.take((size_t)n_tiles * 4), o_ext = ap.take(((size_t)n_tiles + 1) * 4);
     const size_t o_exits = ap.take((size_t)n_tiles * EN_E * 8);
     const size_t o_ne = ap.take(4), o_ol = ap.take(4);
-    const size_t o_el = ap.take((size_t)slots * 4), o_ek = ap.take((size_t)slots * 4), o_eo = ap.take((size_t)slots * 4);
+    const u32 n_lchunks = (slots + EN_LAYOUT_CHUNK - 1) / EN_LAYOUT_CHUNK;
+    const size_t o_el = ap.take((size_t)slots * 4), o_lp = ap.take(8), o_ch = ap.take((size_t)n_lchunks * 16);
     const size_t o_out = ap.take(out_bound + 64);
     const size_t o_ent = ap.take((size_t)n_tiles * 8);
+    const size_t o_segs = ap.take((size_t)n_tiles * EN_SEG_RECS * 4);
     u8* A = nullptr;
     hipError_t e = hipMalloc((void**)&A, ap.total);
     if (e != hipSuccess) return fail(ctx, PQD_E_NOMEM, "hipMalloc failed", e);
@@ -1095,19 +1097,22 @@ int pqd_rle_encode(pqd_ctx* ctx, int width, const void* levels_host, size_t n, v
     EncBlock B;
     memset(&B, 0, sizeof B);
     B.src_off = 0; B.n = (u32)n; B.width = (u32)width; B.elem_base = 0; B.out = A + o_out;
-    const u32 tp[2] = {0, n_tiles}, ep[2] = {0, slots};
+    const u32 tp[2] = {0, n_tiles}, ep[2] = {0, slots}, lp[2] = {0, n_lchunks};
     HIP_TRY(ctx, hipMemsetAsync(A + o_ent, 0xFF, (size_t)n_tiles * 8 + 1, st));
     HIP_TRY(ctx, hipMemsetAsync(A + o_ext, 0, ((size_t)n_tiles + 1) * 4, st));
     if (n) HIP_TRY(ctx, hipMemcpyAsync(A + o_src, levels_host, n, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_blk, &B, sizeof B, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_tp, tp, 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_ep, ep, 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_lp, lp, 8, hipMemcpyHostToDevice, st));
     EncArgs a;
     a.blocks = (EncBlock*)(A + o_blk); a.tile_prefix = (u32*)(A + o_tp); a.elem_prefix = (u32*)(A + o_ep);
     a.n_blocks = 1; a.n_tiles = n_tiles; a.elem_slots = slots;
     a.lead = (u32*)(A + o_lead); a.ext = (u32*)(A + o_ext); a.exits = A + o_exits; a.entries = A + o_ent;
+    a.segs = (u32*)(A + o_segs);
     a.n_elems = (u32*)(A + o_ne); a.out_len = (u32*)(A + o_ol);
-    a.elems = (u32*)(A + o_el); a.elem_k = (u32*)(A + o_ek); a.elem_off = (u32*)(A + o_eo);
+    a.elems = (u32*)(A + o_el);
+    a.lchunk_prefix = (u32*)(A + o_lp); a.n_lchunks = n_lchunks; a.chunks = A + o_ch;
     HIP_TRY(ctx, launch_rle_encode(st, A + o_src, a));
     u32 L = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&L, A + o_ol, 4, hipMemcpyDeviceToHost, st));
@@ -1135,7 +1140,7 @@ int pqd_encode_pages(pqd_ctx* ctx, const pqd_enc_page* pages, size_t n, const vo
     hipStream_t st = ctx->stream;
     std::vector<EncPage> P(n);
     std::vector<EncBlock> B;
-    std::vector<u32> tile_prefix(1, 0), elem_prefix(1, 0), chunk_prefix(1, 0);
+    std::vector<u32> tile_prefix(1, 0), elem_prefix(1, 0), lchunk_prefix(1, 0), chunk_prefix(1, 0);
     size_t bound = 0;
     auto add_block = [&](int64_t off, int64_t nl, int max_level) -> int {
         if (off < 0 || (off & 3) || (u64)off + (u64)nl > src_len) return -1;
@@ -1146,6 +1151,7 @@ int pqd_encode_pages(pqd_ctx* ctx, const pqd_enc_page* pages, size_t n, const vo
         const u64 slots = (u64)nl / 8 + 2, tiles = ((u64)nl + EN_T - 1) / EN_T;
         if ((u64)elem_prefix.back() + slots > 0x7fffffffull || (u64)tile_prefix.back() + tiles > 0x7fffffffull) return -2;
         elem_prefix.push_back(elem_prefix.back() + (u32)slots);
+        lchunk_prefix.push_back(lchunk_prefix.back() + (u32)((slots + EN_LAYOUT_CHUNK - 1) / EN_LAYOUT_CHUNK));
         tile_prefix.push_back(tile_prefix.back() + (u32)tiles);
         bound += 4 + (size_t)slots * (b.width > 5 ? b.width + 1 : 6);
         B.push_back(b);
@@ -1210,8 +1216,10 @@ int pqd_encode_pages(pqd_ctx* ctx, const pqd_enc_page* pages, size_t n, const vo
     const size_t o_tp = ap.take(((size_t)nb + 1) * 4), o_ep = ap.take(((size_t)nb + 1) * 4), o_cp = ap.take((n + 1) * 4);
     const size_t o_lead = ap.take((size_t)n_tiles * 4), o_ext = ap.take(((size_t)n_tiles + 1) * 4);
     const size_t o_exits = ap.take((size_t)n_tiles * EN_E * 8), o_ent = ap.take((size_t)n_tiles * 8);
+    const size_t o_segs = ap.take((size_t)n_tiles * EN_SEG_RECS * 4);
     const size_t o_ne = ap.take((size_t)nb * 4), o_ol = ap.take((size_t)nb * 4);
-    const size_t o_el = ap.take((size_t)slots * 4), o_ek = ap.take((size_t)slots * 4), o_eo = ap.take((size_t)slots * 4);
+    const size_t o_el = ap.take((size_t)slots * 4);
+    const size_t o_lp = ap.take(((size_t)nb + 1) * 4), o_ch = ap.take((size_t)lchunk_prefix.back() * 16);
     const size_t o_out = ap.take(bound + 64);
     const size_t o_sp = ap.take((size_t)chunk_prefix.back() * 16);
     u8* A = nullptr;
@@ -1225,13 +1233,16 @@ int pqd_encode_pages(pqd_ctx* ctx, const pqd_enc_page* pages, size_t n, const vo
     if (nb) HIP_TRY(ctx, hipMemcpyAsync(A + o_blk, B.data(), (size_t)nb * sizeof(EncBlock), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_tp, tile_prefix.data(), ((size_t)nb + 1) * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_ep, elem_prefix.data(), ((size_t)nb + 1) * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(A + o_lp, lchunk_prefix.data(), ((size_t)nb + 1) * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_cp, chunk_prefix.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
     EncArgs a;
     a.blocks = (EncBlock*)(A + o_blk); a.tile_prefix = (u32*)(A + o_tp); a.elem_prefix = (u32*)(A + o_ep);
     a.n_blocks = nb; a.n_tiles = n_tiles; a.elem_slots = slots;
     a.lead = (u32*)(A + o_lead); a.ext = (u32*)(A + o_ext); a.exits = A + o_exits; a.entries = A + o_ent;
+    a.segs = (u32*)(A + o_segs);
     a.n_elems = (u32*)(A + o_ne); a.out_len = (u32*)(A + o_ol);
-    a.elems = (u32*)(A + o_el); a.elem_k = (u32*)(A + o_ek); a.elem_off = (u32*)(A + o_eo);
+    a.elems = (u32*)(A + o_el);
+    a.lchunk_prefix = (u32*)(A + o_lp); a.n_lchunks = lchunk_prefix.back(); a.chunks = A + o_ch;
     HIP_TRY(ctx, launch_rle_encode_layout(st, A + o_src, a));
     HIP_TRY(ctx, launch_encode_pages(st, A + o_src, (EncPage*)(A + o_pg), (u32*)(A + o_cp), (u32)n, chunk_prefix.back(),
                                      (EncBlock*)(A + o_blk), (u32*)(A + o_ol), A + o_out, (u64*)(A + o_sp)));

@@ -149,6 +149,8 @@ hipError_t launch_level_block_sizes(hipStream_t st, const u8* src, const PageRec
 // ---- level encoder (pqd_encode.hip) ----------------------------------------------------------
 constexpr u32 EN_T = 2048;  // level positions per encoder tile
 constexpr u32 EN_E = 9;     // chain entries per tile: its first 8 positions + the end of a run that reaches into it
+constexpr u32 EN_LAYOUT_CHUNK = 2048;  // elements per workgroup of the layout and write kernels
+constexpr u32 EN_SEG_RECS = (EN_T / 256) * EN_E;  // 8 segments of 256 positions, EN_E walkers each
 struct EncBlock {
     u64 src_off;    // first level of the block (4-byte aligned)
     u32 n;          // levels
@@ -161,13 +163,17 @@ struct EncArgs {
     const EncBlock* blocks;
     const u32* tile_prefix;  // n_blocks + 1
     const u32* elem_prefix;  // n_blocks + 1 (== elem_base of every block, then the total)
+    const u32* lchunk_prefix;  // n_blocks + 1: layout chunks (EN_LAYOUT_CHUNK element slots each) in front of every block
+    u32 n_lchunks;
+    void* chunks;            // n_lchunks * 16 bytes
     u32 n_blocks, n_tiles, elem_slots;
     u32* lead;               // n_tiles
     u32* ext;                // n_tiles + 1
     void* exits;             // n_tiles * EN_E * 8 bytes
     void* entries;           // n_tiles * 8 bytes, reset to 0xFF
+    u32* segs;               // n_tiles * EN_SEG_RECS: per tile, the exits of the segment walkers
     u32 *n_elems, *out_len;  // n_blocks
-    u32 *elems, *elem_k, *elem_off;  // elem_slots each
+    u32* elems;              // elem_slots
 };
 hipError_t launch_rle_encode(hipStream_t st, const u8* src, const EncArgs& a);
 hipError_t launch_rle_encode_layout(hipStream_t st, const u8* src, const EncArgs& a);

@@ -13,12 +13,15 @@
 // 9 entries.
 //   k_enc_lead     per tile: how far the equal run of the previous tile's last value reaches into it
 //   k_enc_ext      per block: the same, continued across whole tiles (one backward pass over the tiles)
-//   k_enc_exits    per tile, one lane per entry: where the chain leaves the tile, elements passed
+//   k_enc_exits    per tile: where the chain leaves the tile from each entry, elements passed (the tile is
+//                  walked as 8 segments with 9 entries each at once, then the entries hop through them)
 //   k_enc_hop      per block: true entry and element index of every tile
-//   k_enc_mark     per tile: walks the true chain, one record per element (position, RLE flag)
-//   k_enc_layout   per block: byte offset of every element (max-scan for the bit-packed group index
-//                  inside its run of at most 63, then a sum-scan of the element sizes)
-//   k_enc_write    per element: header / value bytes or the packed group; block length in front
+//   k_enc_mark     per tile: walks the true chain, one lane per segment, one record per element
+//                  (position, RLE flag)
+//   k_enc_chunks, k_enc_chunk_carry   byte offset of every chunk of 2048 elements (the bit-packed group index
+//                  inside its run of at most 63 groups decides where headers go)
+//   k_enc_write    per chunk: element offsets, then header / value bytes or the packed group per element;
+//                  block length in front
 #include "pqd_device.h"
 
 namespace pqd {
@@ -155,84 +158,186 @@ static __device__ __forceinline__ u32 enc_step(const u32* s_mask, const u32* s_n
 
 struct EncExit { u32 pos; u32 cnt; };
 
-__global__ __launch_bounds__(64) void k_enc_exits(const u8* __restrict__ src, const EncBlock* __restrict__ blocks,
-                                                  const u32* __restrict__ tile_prefix, u32 n_blocks,
-                                                  const u32* __restrict__ lead, const u32* __restrict__ ext,
-                                                  EncExit* __restrict__ exits) {
+// A tile is walked in EN_NSEG segments of EN_SEG positions at once.  What holds for a tile holds for a
+// segment: the chain enters it at one of its first 8 positions or where the equal run that covers the
+// position in front of it ends, so EN_E walkers per segment cover every way in, each takes at most
+// EN_SEG / 8 steps, and the tile's exits follow by hopping through the segment table.  The table is kept
+// for k_enc_mark: exit (tile relative, EN_T = beyond the tile, 0xFFFF = walker unused) | elements << 16.
+constexpr u32 EN_SEG = 256, EN_NSEG = EN_T / EN_SEG, EN_WALKERS = EN_NSEG * EN_E;
+constexpr u32 EN_NONE = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(128) void k_enc_exits(const u8* __restrict__ src, const EncBlock* __restrict__ blocks,
+                                                   const u32* __restrict__ tile_prefix, u32 n_blocks,
+                                                   const u32* __restrict__ lead, const u32* __restrict__ ext,
+                                                   EncExit* __restrict__ exits, u32* __restrict__ segs) {
+    static_assert(EN_WALKERS <= 128 && EN_WALKERS == EN_SEG_RECS, "one thread per walker; the table the host sizes");
     __shared__ u32 s_mask[64], s_next[64];
-    const u32 tile = blockIdx.x, lane = threadIdx.x;
+    __shared__ u32 s_xpos[EN_WALKERS], s_xcnt[EN_WALKERS];
+    const u32 tile = blockIdx.x, tid = threadIdx.x;
     u32 lo = 0, hi = n_blocks;
     while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (tile_prefix[mid] <= tile) lo = mid; else hi = mid; }
     const EncBlock B = blocks[lo];
     const u32 t = tile - tile_prefix[lo], tb = t * EN_T, n = B.n;
-    const u32 te = tb + EN_T;
-    build_masks(src + B.src_off, n, tb, lane, s_mask, s_next);
+    const u32 te = tb + EN_T, lim = te < n ? te : n;
+    if (tid < 64) build_masks(src + B.src_off, n, tb, tid, s_mask, s_next);
     __syncthreads();
-    if (lane >= EN_E) return;
-    // entries 0..7: the first 8 positions; entry 8: where the run of the previous tile's last value ends
-    u32 p = lane < 8 ? tb + lane : tb + lead[tile];
-    if (lane == 8 && (lead[tile] < 8 || lead[tile] >= EN_T)) p = 0xFFFFFFFFu;  // covered by entries 0..7 / no entry
-    u32 cnt = 0;
     const u32* ext_next = ext + tile + 1;  // the array has one spare entry
-    while (p < te && p < n) {
-        bool rle;
-        p = enc_step(s_mask, s_next, ext_next, tb, p - tb, n, rle);
-        cnt++;
+    const u32 ld = lead[tile];
+    // tile entries 0..7: the first 8 positions; entry 8: where the run of the previous tile's last value
+    // ends (below 8 it is one of the first; a run over the whole tile never enters it)
+    const u32 lead_entry = ld >= 8 && ld < EN_T ? tb + ld : EN_NONE;
+    if (tid < EN_WALKERS) {
+        const u32 s = tid / EN_E, c = tid - s * EN_E;
+        u32 p = EN_NONE;
+        if (c < 8) p = tb + s * EN_SEG + c;
+        else if (s == 0) p = lead_entry;
+        else if (tb + s * EN_SEG - 1 < n) {
+            const u32 re = run_end_in_tile(s_mask, s_next, s * EN_SEG - 1);
+            u32 end = tb + re;
+            if (re == EN_T && te < n) end = te + *ext_next;
+            if (end > n) end = n;
+            if (end >= tb + s * EN_SEG + 8) p = end;
+        }
+        const u32 start = p;
+        const u32 seg_end = tb + (s + 1) * EN_SEG < lim ? tb + (s + 1) * EN_SEG : lim;
+        u32 cnt = 0;
+        while (p < seg_end) {
+            bool rle;
+            p = enc_step(s_mask, s_next, ext_next, tb, p - tb, n, rle);
+            cnt++;
+        }
+        s_xpos[tid] = p; s_xcnt[tid] = cnt;
+        const u32 rel = start == EN_NONE ? 0xFFFFu : p >= te ? EN_T : p - tb;
+        segs[(u64)tile * EN_WALKERS + tid] = rel | (cnt << 16);
     }
-    EncExit x;
-    x.pos = p; x.cnt = cnt;
-    exits[(u64)tile * EN_E + lane] = x;
+    __syncthreads();
+    if (tid < EN_E) {
+        u32 p = tid < 8 ? tb + tid : lead_entry, cnt = 0;
+        for (u32 h = 0; h < EN_NSEG && p < lim; h++) {  // every hop lands in a later segment
+            const u32 rel = p - tb, s = rel / EN_SEG, off = rel - s * EN_SEG;
+            const u32 w = s * EN_E + (off < 8 ? off : 8);  // off >= 8: the end of a run, walker 8
+            p = s_xpos[w]; cnt += s_xcnt[w];
+        }
+        EncExit x;
+        x.pos = p; x.cnt = cnt;
+        exits[(u64)tile * EN_E + tid] = x;
+    }
 }
 
 // True entry (block position, element index) of every tile; total elements of the block.  One workgroup
-// per block: the block's exit table is staged in LDS when it fits (a 1M-level page has 489 tiles), so that
-// the one thread that follows the chain pays LDS latency per tile instead of a global load.
-constexpr u32 EN_HOP_LDS_TILES = 800;
+// per block.  When the block's exit table fits in LDS (a 1M-level page has 489 tiles) the walk has two
+// levels, as in the decoder: groups of EN_HG tiles have the same 9 ways in as a tile (the first 8 positions,
+// or the end of the run that covers the position in front of the group), so one thread per (group, entry)
+// composes the group's exits, one thread follows the chain from group to group, and one thread per group
+// writes the entries of its tiles.  Larger blocks are walked tile by tile by one thread.
+constexpr u32 EN_HOP_LDS_TILES = 768, EN_HG = 8, EN_HOP_GROUPS = EN_HOP_LDS_TILES / EN_HG;
 __global__ __launch_bounds__(256) void k_enc_hop(const EncBlock* __restrict__ blocks, const u32* __restrict__ tile_prefix, u32 n_blocks,
-                                                 const u32* __restrict__ lead, const EncExit* __restrict__ exits,
+                                                 const u32* __restrict__ ext, const EncExit* __restrict__ exits,
                                                  EncExit* __restrict__ entries, u32* __restrict__ n_elems) {
     __shared__ EncExit s_ex[EN_HOP_LDS_TILES * EN_E];
-    const u32 b = blockIdx.x;
+    __shared__ EncExit s_gx[EN_HOP_GROUPS * EN_E], s_gent[EN_HOP_GROUPS];
+    const u32 b = blockIdx.x, tid = threadIdx.x;
     const u32 n = blocks[b].n, t0 = tile_prefix[b], nt = tile_prefix[b + 1] - t0;
-    const bool staged = nt <= EN_HOP_LDS_TILES;
-    if (staged) {
-        for (u32 i = threadIdx.x; i < nt * EN_E; i += 256) s_ex[i] = exits[(u64)t0 * EN_E + i];
-        __syncthreads();
+    if (nt > EN_HOP_LDS_TILES) {
+        if (tid != 0) return;
+        u32 p = 0, cnt = 0;
+        while (p < n) {
+            const u32 t = p / EN_T, off = p - t * EN_T;
+            EncExit e;
+            e.pos = p; e.cnt = cnt;
+            entries[t0 + t] = e;
+            const EncExit x = exits[(u64)t0 * EN_E + t * EN_E + (off < 8 ? off : 8)];  // off >= 8 is the run end: entry 8
+            p = x.pos;
+            cnt += x.cnt;
+        }
+        n_elems[b] = cnt;
+        return;
     }
-    if (threadIdx.x != 0) return;
-    u32 p = 0, cnt = 0;
-    while (p < n) {
-        const u32 t = p / EN_T, off = p - t * EN_T;
-        EncExit e;
-        e.pos = p; e.cnt = cnt;
-        entries[t0 + t] = e;
-        const u32 slot = t * EN_E + (off < 8 ? off : 8);  // off >= 8 is the run end: entry 8
-        const EncExit x = staged ? s_ex[slot] : exits[(u64)t0 * EN_E + slot];
-        p = x.pos;
-        cnt += x.cnt;
+    const u32 ng = (nt + EN_HG - 1) / EN_HG;
+    constexpr u32 GSPAN = EN_HG * EN_T;
+    for (u32 i = tid; i < nt * EN_E; i += 256) s_ex[i] = exits[(u64)t0 * EN_E + i];
+    for (u32 i = tid; i < ng; i += 256) s_gent[i].pos = EN_NONE;
+    __syncthreads();
+    for (u32 i = tid; i < ng * EN_E; i += 256) {
+        const u32 g = i / EN_E, e = i - g * EN_E, gb = g * GSPAN;
+        const u32 gend = gb + GSPAN < n ? gb + GSPAN : n;
+        u32 p = EN_NONE, cnt = 0;
+        if (e < 8) p = gb + e;
+        else if (g > 0) {
+            const u32 x = ext[t0 + g * EN_HG];  // how far the run in front of the group reaches into it (and beyond)
+            if (x >= 8) p = gb + x;
+        }
+        while (p < gend) {
+            const u32 t = p / EN_T, off = p - t * EN_T;
+            const EncExit x = s_ex[t * EN_E + (off < 8 ? off : 8)];
+            p = x.pos; cnt += x.cnt;
+        }
+        s_gx[i].pos = p; s_gx[i].cnt = cnt;
     }
-    n_elems[b] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        u32 p = 0, cnt = 0;
+        while (p < n) {
+            const u32 g = p / GSPAN, off = p - g * GSPAN;
+            s_gent[g].pos = p; s_gent[g].cnt = cnt;
+            const EncExit x = s_gx[g * EN_E + (off < 8 ? off : 8)];
+            p = x.pos; cnt += x.cnt;
+        }
+        n_elems[b] = cnt;
+    }
+    __syncthreads();
+    for (u32 g = tid; g < ng; g += 256) {
+        u32 p = s_gent[g].pos, cnt = s_gent[g].cnt;
+        const u32 gend = (g + 1) * GSPAN < n ? (g + 1) * GSPAN : n;
+        while (p < gend) {  // EN_NONE: the chain steps over the whole group
+            const u32 t = p / EN_T, off = p - t * EN_T;
+            EncExit e;
+            e.pos = p; e.cnt = cnt;
+            entries[t0 + t] = e;
+            const EncExit x = s_ex[t * EN_E + (off < 8 ? off : 8)];
+            p = x.pos; cnt += x.cnt;
+        }
+    }
 }
 
-// Element records: position | RLE flag in bit 31 (levels per block stay below 2^31).
+// Element records: position | RLE flag in bit 31 (levels per block stay below 2^31).  Lane 0 hops from the
+// tile's true entry through the segment table of k_enc_exits, which yields where the true chain enters every
+// segment and how many elements precede it; then one lane per segment walks and writes its records.
 __global__ __launch_bounds__(64) void k_enc_mark(const u8* __restrict__ src, const EncBlock* __restrict__ blocks,
                                                  const u32* __restrict__ tile_prefix, u32 n_blocks,
                                                  const u32* __restrict__ ext, const EncExit* __restrict__ entries,
-                                                 u32* __restrict__ elems) {
+                                                 const u32* __restrict__ segs, u32* __restrict__ elems) {
     __shared__ u32 s_mask[64], s_next[64];
+    __shared__ u32 s_seg[EN_WALKERS], s_entp[EN_NSEG], s_entc[EN_NSEG];
     const u32 tile = blockIdx.x, lane = threadIdx.x;
     const EncExit ent = entries[tile];
-    if (ent.pos == 0xFFFFFFFFu) return;  // the true chain has no boundary in this tile
+    if (ent.pos == EN_NONE) return;  // the true chain has no boundary in this tile
     u32 lo = 0, hi = n_blocks;
     while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (tile_prefix[mid] <= tile) lo = mid; else hi = mid; }
     const EncBlock B = blocks[lo];
-    const u32 t = tile - tile_prefix[lo], tb = t * EN_T, n = B.n, te = tb + EN_T;
+    const u32 t = tile - tile_prefix[lo], tb = t * EN_T, n = B.n, te = tb + EN_T, lim = te < n ? te : n;
     build_masks(src + B.src_off, n, tb, lane, s_mask, s_next);
+    for (u32 i = lane; i < EN_WALKERS; i += 64) s_seg[i] = segs[(u64)tile * EN_WALKERS + i];
+    if (lane < EN_NSEG) s_entp[lane] = EN_NONE;
     __syncthreads();
-    if (lane != 0) return;
-    u32* out = elems + B.elem_base + ent.cnt;
-    u32 p = ent.pos, i = 0;
-    while (p < te && p < n) {
+    if (lane == 0) {
+        u32 p = ent.pos, cnt = 0;
+        for (u32 h = 0; h < EN_NSEG && p < lim; h++) {
+            const u32 rel = p - tb, s = rel / EN_SEG, off = rel - s * EN_SEG;
+            s_entp[s] = p; s_entc[s] = cnt;
+            const u32 r = s_seg[s * EN_E + (off < 8 ? off : 8)], x = r & 0xFFFFu;
+            cnt += r >> 16;
+            p = x >= EN_T ? EN_NONE : tb + x;
+        }
+    }
+    __syncthreads();
+    if (lane >= EN_NSEG) return;
+    u32 p = s_entp[lane];
+    if (p == EN_NONE) return;
+    const u32 seg_end = tb + (lane + 1) * EN_SEG < lim ? tb + (lane + 1) * EN_SEG : lim;
+    u32* out = elems + B.elem_base + ent.cnt + s_entc[lane];
+    u32 i = 0;
+    while (p < seg_end) {
         bool rle;
         const u32 q = enc_step(s_mask, s_next, ext + tile + 1, tb, p - tb, n, rle);
         out[i++] = p | (rle ? 0x80000000u : 0u);
@@ -240,72 +345,146 @@ __global__ __launch_bounds__(64) void k_enc_mark(const u8* __restrict__ src, con
     }
 }
 
-// Byte offset of every element of a block, one workgroup per block.
+// Layout: the byte offset of every element, in chunks of EN_LC elements so that the whole device takes part.
 //   bit-packed element e: k = e - 1 - (index of the last RLE element before e); it opens a header when
 //   k % 63 == 0 (writeOrAppendBitPackedRun: a new run after an RLE run or after 63 groups)
 //   sizes: RLE = leb128(count << 1) + one value byte unless width is 0; bit-packed = width bytes (+1 header)
-__global__ __launch_bounds__(1024) void k_enc_layout(const EncBlock* __restrict__ blocks, const u32* __restrict__ n_elems,
-                                                     const u32* __restrict__ elems, u32* __restrict__ elem_k,
-                                                     u32* __restrict__ elem_off, u32* __restrict__ out_len) {
-    __shared__ int s_last[16];
-    __shared__ u32 s_sum[16];
-    const EncBlock B = blocks[blockIdx.x];
-    const u32 ne = n_elems[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32* el = elems + B.elem_base;
-    u32* ek = elem_k + B.elem_base;
-    u32* eo = elem_off + B.elem_base;
-    const u32 bw = B.width ? 1u : 0u;
-    int carry_last = -1;  // index of the last RLE element before the current batch
-    u32 carry_off = 0;
-    for (u32 base = 0; base < ne; base += 1024) {
-        const u32 e = base + tid;
-        const bool valid = e < ne;
-        const u32 rec = valid ? el[e] : 0;
-        const bool rle = valid && (rec & 0x80000000u);
-        // inclusive max-scan of (rle ? e : -1)
-        int last = rle ? (int)e : -1;
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(last, d);
-            if (lane >= (u32)d && t > last) last = t;
-        }
-        if (lane == 63) s_last[wv] = last;
-        __syncthreads();
-        int pre = carry_last;
-        for (u32 q = 0; q < wv; q++) pre = s_last[q] > pre ? s_last[q] : pre;
-        int blk_last = carry_last;
-        for (u32 q = 0; q < 16; q++) blk_last = s_last[q] > blk_last ? s_last[q] : blk_last;
-        last = last > pre ? last : pre;  // index of the last RLE element at or before e
-        u32 size = 0, k = 0;
-        if (valid) {
-            if (rle) {
-                const u32 nextp = e + 1 < ne ? (el[e + 1] & 0x7FFFFFFFu) : B.n;
-                const u32 h = (nextp - (rec & 0x7FFFFFFFu)) << 1;  // a run is shorter than 2^31 values
-                size = (h < (1u << 7) ? 1u : h < (1u << 14) ? 2u : h < (1u << 21) ? 3u : h < (1u << 28) ? 4u : 5u) + bw;
-            } else {
-                k = e - 1 - (u32)last;  // last == -1: e
-                size = B.width + (k % 63 == 0 ? 1u : 0u);
-            }
-            ek[e] = k;
-        }
-        // exclusive sum-scan of the sizes
-        u32 incl = size;
-        for (int d = 1; d < 64; d <<= 1) {
-            const u32 t = __shfl_up(incl, d);
-            if (lane >= (u32)d) incl += t;
-        }
-        if (lane == 63) s_sum[wv] = incl;
-        __syncthreads();
-        u32 pre_s = carry_off, tot = 0;
-        for (u32 q = 0; q < 16; q++) {
-            if (q < wv) pre_s += s_sum[q];
-            tot += s_sum[q];
-        }
-        if (valid) eo[e] = pre_s + incl - size;
-        carry_off += tot;
-        carry_last = blk_last;
-        __syncthreads();
+// A chunk on its own knows everything except the headers of its leading bit-packed elements (their k counts
+// from an RLE element of an earlier chunk), and those follow in closed form from how many they are and the k of
+// the first.  So: k_enc_chunks sums each chunk without them, k_enc_chunk_carry scans the chunks of a block
+// (last RLE element so far, bytes so far), and k_enc_write redoes the chunk's scan with both known and writes.
+struct EncChunk {
+    u32 sum;   // bytes of the chunk without the headers of its leading bit-packed elements
+    u32 head;  // number of those elements
+    int last;  // k_enc_chunks: last RLE element of the chunk (-1 none); after the carry: the last one BEFORE the chunk
+    u32 base;  // after the carry: byte offset of the chunk
+};
+static __device__ __forceinline__ u32 mult63(u32 x) { return (x + 62) / 63; }  // multiples of 63 in [0, x)
+
+// One chunk, 256 threads: wave wv, row j, lane l holds element c0 + wv * 512 + j * 64 + l, so loads are
+// coalesced and a wave's rows are consecutive.  Yields per element its record, the record after it, its k
+// and its size.  FINAL = false: `carry` is unknown, leading bit-packed elements get size `width` and are
+// counted in head.  Returns the chunk's last RLE element (-1: none).
+template <bool FINAL>
+static __device__ __forceinline__ int chunk_sizes(const u32* __restrict__ el, u32 ne, u32 c0, u32 bn, u32 width, int carry,
+                                                  u32 tid, int* s_last, u32 (&rec)[8], u32 (&nxt)[8], u32 (&kk)[8],
+                                                  u32 (&size)[8], u32& head) {
+    const u32 lane = tid & 63, wv = tid >> 6;
+    const u64 lt = (1ull << lane) - 1;
+    const u32 bw = width ? 1u : 0u;
+    int before[8];
+    int rowcarry = -1;
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+        const u32 r0 = c0 + wv * 512 + j * 64, e = r0 + lane;
+        rec[j] = e < ne ? el[e] : 0;
+        nxt[j] = e + 1 < ne ? el[e + 1] : bn;
+        // elements of a row are consecutive: the last RLE element before me is the highest set bit below my lane
+        const u64 b = __ballot((rec[j] & 0x80000000u) != 0);
+        const u64 m = b & lt;
+        before[j] = m ? (int)(r0 + 63 - (u32)__builtin_clzll(m)) : rowcarry;
+        if (b) rowcarry = (int)(r0 + 63 - (u32)__builtin_clzll(b));
     }
-    if (tid == 0) out_len[blockIdx.x] = carry_off;
+    if (lane == 0) s_last[wv] = rowcarry;
+    __syncthreads();
+    int cross = -1, chunk_last = -1;
+    for (u32 q = 0; q < 4; q++) {
+        if (q < wv && s_last[q] > cross) cross = s_last[q];
+        if (s_last[q] > chunk_last) chunk_last = s_last[q];
+    }
+    head = 0;
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+        const u32 e = c0 + wv * 512 + j * 64 + lane;
+        int bf = before[j] > cross ? before[j] : cross;
+        size[j] = 0; kk[j] = 0;
+        if (e < ne) {
+            if (rec[j] & 0x80000000u) {
+                const u32 h = ((nxt[j] & 0x7FFFFFFFu) - (rec[j] & 0x7FFFFFFFu)) << 1;  // a run is shorter than 2^31 values
+                size[j] = (h < (1u << 7) ? 1u : h < (1u << 14) ? 2u : h < (1u << 21) ? 3u : h < (1u << 28) ? 4u : 5u) + bw;
+            } else if (!FINAL && bf < 0) {
+                size[j] = width;
+                head++;
+            } else {
+                if (bf < 0) bf = carry;
+                kk[j] = e - 1 - (u32)bf;  // bf == -1: e
+                size[j] = width + (kk[j] % 63 == 0 ? 1u : 0u);
+            }
+        }
+    }
+    return chunk_last;
+}
+
+constexpr u32 EN_LC = EN_LAYOUT_CHUNK;
+static __device__ __forceinline__ u32 find_block(const u32* __restrict__ prefix, u32 n_blocks, u32 x) {
+    u32 lo = 0, hi = n_blocks;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (prefix[mid] <= x) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_enc_chunks(const EncBlock* __restrict__ blocks, const u32* __restrict__ lchunk_prefix,
+                                                    u32 n_blocks, const u32* __restrict__ n_elems, const u32* __restrict__ elems,
+                                                    EncChunk* __restrict__ chunks) {
+    __shared__ int s_last[4];
+    __shared__ u32 s_sum[4], s_head[4];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 blk = find_block(lchunk_prefix, n_blocks, blockIdx.x);
+    const u32 c0 = (blockIdx.x - lchunk_prefix[blk]) * EN_LC, ne = n_elems[blk];
+    if (c0 >= ne) return;
+    const EncBlock B = blocks[blk];
+    u32 rec[8], nxt[8], kk[8], size[8], head;
+    const int last = chunk_sizes<false>(elems + B.elem_base, ne, c0, B.n, B.width, -1, tid, s_last, rec, nxt, kk, size, head);
+    u32 sum = 0;
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) sum += size[j];
+    for (int d = 32; d > 0; d >>= 1) { sum += __shfl_xor(sum, d); head += __shfl_xor(head, d); }
+    if (lane == 0) { s_sum[wv] = sum; s_head[wv] = head; }
+    __syncthreads();
+    if (tid == 0) {
+        EncChunk c;
+        c.sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        c.head = s_head[0] + s_head[1] + s_head[2] + s_head[3];
+        c.last = last; c.base = 0;
+        chunks[blockIdx.x] = c;
+    }
+}
+
+// One wave per block: scans the block's chunks, 64 at a time.
+__global__ __launch_bounds__(64) void k_enc_chunk_carry(const u32* __restrict__ lchunk_prefix, const u32* __restrict__ n_elems,
+                                                        EncChunk* __restrict__ chunks, u32* __restrict__ out_len) {
+    const u32 b = blockIdx.x, lane = threadIdx.x;
+    const u32 ne = n_elems[b], nc = (ne + EN_LC - 1) / EN_LC;
+    EncChunk* ch = chunks + lchunk_prefix[b];
+    int carry_before = -1;
+    u32 carry_off = 0;
+    for (u32 cb = 0; cb < nc; cb += 64) {
+        const u32 c = cb + lane;
+        const bool valid = c < nc;
+        EncChunk x;
+        x.sum = 0; x.head = 0; x.last = -1; x.base = 0;
+        if (valid) x = ch[c];
+        int incl = x.last;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= (u32)d && t > incl) incl = t;
+        }
+        int before = __shfl_up(incl, 1);
+        if (lane == 0) before = -1;
+        if (carry_before > before) before = carry_before;
+        // the leading bit-packed elements of the chunk: the first has k0, every multiple of 63 is a header
+        const u32 k0 = c * EN_LC - 1 - (u32)before;
+        const u32 total = valid ? x.sum + mult63(k0 + x.head) - mult63(k0) : 0;
+        u32 incl_s = total;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(incl_s, d);
+            if (lane >= (u32)d) incl_s += t;
+        }
+        if (valid) { ch[c].last = before; ch[c].base = carry_off + incl_s - total; }
+        const int top = __shfl(incl, 63);
+        if (top > carry_before) carry_before = top;
+        carry_off += __shfl(incl_s, 63);
+    }
+    if (lane == 0) out_len[b] = carry_off;
 }
 
 // bitpack.Pack for one group (internal/bitpack/bitpack.go:20-74, generated by cmd/bitpackgen: value j
@@ -321,38 +500,61 @@ static __device__ __forceinline__ void pack_group(const u8* v, u32 p, u32 n, u32
 }
 
 __global__ __launch_bounds__(256) void k_enc_write(const u8* __restrict__ src, const EncBlock* __restrict__ blocks,
-                                                   const u32* __restrict__ elem_prefix, u32 n_blocks,
+                                                   const u32* __restrict__ lchunk_prefix, u32 n_blocks,
                                                    const u32* __restrict__ n_elems, const u32* __restrict__ elems,
-                                                   const u32* __restrict__ elem_k, const u32* __restrict__ elem_off,
-                                                   const u32* __restrict__ out_len) {
-    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;  // slot in the element arrays
-    u32 lo = 0, hi = n_blocks;
-    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (elem_prefix[mid] <= g) lo = mid; else hi = mid; }
-    const EncBlock B = blocks[lo];
-    const u32 e = g - elem_prefix[lo], ne = n_elems[lo];
+                                                   const EncChunk* __restrict__ chunks, const u32* __restrict__ out_len) {
+    __shared__ int s_last[4];
+    __shared__ u32 s_sum[4];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 blk = find_block(lchunk_prefix, n_blocks, blockIdx.x);
+    const u32 c0 = (blockIdx.x - lchunk_prefix[blk]) * EN_LC, ne = n_elems[blk];
+    const EncBlock B = blocks[blk];
     u8* out = B.out;
-    if (e == 0) {  // int32 LE length in front of the runs (rle.go:153-155); also for an empty block
-        const u32 L = out_len[lo];
+    if (c0 == 0 && tid == 0) {  // int32 LE length in front of the runs (rle.go:153-155); also for an empty block
+        const u32 L = out_len[blk];
         out[0] = (u8)L; out[1] = (u8)(L >> 8); out[2] = (u8)(L >> 16); out[3] = (u8)(L >> 24);
     }
-    if (e >= ne) return;
+    if (c0 >= ne) return;
+    const EncChunk ch = chunks[blockIdx.x];
+    u32 rec[8], nxt[8], kk[8], size[8], head;
+    chunk_sizes<true>(elems + B.elem_base, ne, c0, B.n, B.width, ch.last, tid, s_last, rec, nxt, kk, size, head);
+    // offsets: sum-scan in element order (rows of a wave, then the waves)
+    u32 off[8], rowbase = 0;
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+        u32 incl = size[j];
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(incl, d);
+            if (lane >= (u32)d) incl += t;
+        }
+        off[j] = rowbase + incl - size[j];
+        rowbase += __shfl(incl, 63);
+    }
+    if (lane == 0) s_sum[wv] = rowbase;
+    __syncthreads();
+    u32 wbase = ch.base;
+    for (u32 q = 0; q < wv; q++) wbase += s_sum[q];
     const u8* v = src + B.src_off;
-    const u32* el = elems + B.elem_base;
-    const u32 rec = el[e], p = rec & 0x7FFFFFFFu, off = elem_off[B.elem_base + e];
-    u8* o = out + 4 + off;
-    if (rec & 0x80000000u) {
-        const u32 nextp = e + 1 < ne ? (el[e + 1] & 0x7FFFFFFFu) : B.n;
-        u32 h = (nextp - p) << 1;
-        while (h >= 0x80) { *o++ = (u8)(h | 0x80); h >>= 7; }
-        *o++ = (u8)h;
-        if (B.width) *o = v[p];
-    } else {
-        const u32 k = elem_k[B.elem_base + e], kk = k % 63;
-        if (kk == 0) o++;  // the header byte of the run this group opens
-        pack_group(v, p, B.n, B.width, o);
-        // the last group of a bit-packed run writes the run's header: groups << 1 | 1
-        const bool last = kk == 62 || e + 1 == ne || (el[e + 1] & 0x80000000u);
-        if (last) out[4 + elem_off[B.elem_base + e - kk]] = (u8)(((kk + 1) << 1) | 1);
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) {
+        const u32 e = c0 + wv * 512 + j * 64 + lane;
+        if (e >= ne) continue;
+        const u32 p = rec[j] & 0x7FFFFFFFu, o0 = wbase + off[j];
+        u8* o = out + 4 + o0;
+        if (rec[j] & 0x80000000u) {
+            u32 h = ((nxt[j] & 0x7FFFFFFFu) - p) << 1;
+            while (h >= 0x80) { *o++ = (u8)(h | 0x80); h >>= 7; }
+            *o++ = (u8)h;
+            if (B.width) *o = v[p];
+        } else {
+            const u32 m = kk[j] % 63;
+            if (m == 0) o++;  // the header byte of the run this group opens
+            pack_group(v, p, B.n, B.width, o);
+            // the last group of a bit-packed run writes the run's header, groups << 1 | 1, which sits in front of
+            // the run's first group: m groups of `width` bytes and the header byte itself back from here
+            const bool last = m == 62 || e + 1 == ne || (nxt[j] & 0x80000000u);
+            if (last) out[4 + o0 - (m ? m * B.width + 1 : 0)] = (u8)(((m + 1) << 1) | 1);
+        }
     }
 }
 
@@ -567,28 +769,30 @@ hipError_t launch_rle_encode_layout(hipStream_t st, const u8* src, const EncArgs
         ENC_CHECK();
         hipLaunchKernelGGL(k_enc_ext, dim3(a.n_blocks), dim3(1024), 0, st, a.blocks, a.tile_prefix, a.n_blocks, a.lead, a.ext);
         ENC_CHECK();
-        hipLaunchKernelGGL(k_enc_exits, dim3(a.n_tiles), dim3(64), 0, st, src, a.blocks, a.tile_prefix, a.n_blocks, a.lead, a.ext,
-                           (EncExit*)a.exits);
+        hipLaunchKernelGGL(k_enc_exits, dim3(a.n_tiles), dim3(128), 0, st, src, a.blocks, a.tile_prefix, a.n_blocks, a.lead, a.ext,
+                           (EncExit*)a.exits, a.segs);
         ENC_CHECK();
     }
-    hipLaunchKernelGGL(k_enc_hop, dim3(a.n_blocks), dim3(256), 0, st, a.blocks, a.tile_prefix, a.n_blocks, a.lead,
+    hipLaunchKernelGGL(k_enc_hop, dim3(a.n_blocks), dim3(256), 0, st, a.blocks, a.tile_prefix, a.n_blocks, a.ext,
                        (const EncExit*)a.exits, (EncExit*)a.entries, a.n_elems);
     ENC_CHECK();
     if (a.n_tiles) {
         hipLaunchKernelGGL(k_enc_mark, dim3(a.n_tiles), dim3(64), 0, st, src, a.blocks, a.tile_prefix, a.n_blocks, a.ext,
-                           (const EncExit*)a.entries, a.elems);
+                           (const EncExit*)a.entries, a.segs, a.elems);
         ENC_CHECK();
     }
-    hipLaunchKernelGGL(k_enc_layout, dim3(a.n_blocks), dim3(1024), 0, st, a.blocks, a.n_elems, a.elems, a.elem_k, a.elem_off, a.out_len);
+    hipLaunchKernelGGL(k_enc_chunks, dim3(a.n_lchunks), dim3(256), 0, st, a.blocks, a.lchunk_prefix, a.n_blocks, a.n_elems, a.elems,
+                       (EncChunk*)a.chunks);
+    ENC_CHECK();
+    hipLaunchKernelGGL(k_enc_chunk_carry, dim3(a.n_blocks), dim3(64), 0, st, a.lchunk_prefix, a.n_elems, (EncChunk*)a.chunks, a.out_len);
     ENC_CHECK();
     return hipSuccess;
 }
 // write: the bytes, to EncBlock.out of every block
 hipError_t launch_rle_encode_write(hipStream_t st, const u8* src, const EncArgs& a) {
     if (a.n_blocks == 0) return hipSuccess;
-    const u32 slots = a.elem_slots ? a.elem_slots : 1;
-    hipLaunchKernelGGL(k_enc_write, dim3((slots + 255) / 256), dim3(256), 0, st, src, a.blocks, a.elem_prefix, a.n_blocks, a.n_elems,
-                       a.elems, a.elem_k, a.elem_off, a.out_len);
+    hipLaunchKernelGGL(k_enc_write, dim3(a.n_lchunks), dim3(256), 0, st, src, a.blocks, a.lchunk_prefix, a.n_blocks, a.n_elems,
+                       a.elems, (const EncChunk*)a.chunks, a.out_len);
     ENC_CHECK();
     return hipSuccess;
 }

@@ -76,6 +76,21 @@ def test_runs_across_many_tiles(ctx):
         assert R.rle_encode(ctx, 2, lv[:cut]) == bytes(O.rle_encode(2, lv[:cut]))
 
 
+def test_runs_around_layout_chunk_boundaries(ctx):
+    """Bit-packed runs (headers every 63 groups, counted from the last RLE run) that start in one chunk of 2048
+    elements and go on through the next ones; the RLE run that restarts the count sits on either side of a
+    chunk boundary."""
+    alt = np.tile(np.array([0, 1], np.uint8), 4)  # one group that never opens an RLE run
+    for width in (1, 3):
+        for groups in (2046, 2047, 2048, 2049, 4095, 4096, 4097):
+            for run in (8, 16, 24, 8 * 2048):
+                lv = np.concatenate([np.tile(alt, groups), np.full(run, 1, np.uint8), np.tile(alt, 5000), np.full(9, 0, np.uint8)])
+                assert R.rle_encode(ctx, width, lv) == bytes(O.rle_encode(width, lv)), (width, groups, run)
+    # no RLE run at all: every chunk's count comes from the block start
+    lv = np.tile(alt, 3 * 2048 + 5)
+    assert R.rle_encode(ctx, 2, lv) == bytes(O.rle_encode(2, lv))
+
+
 @pytest.mark.parametrize("width", [5, 6, 7, 8])
 def test_wide_levels_round_trip(ctx, width):
     """Widths the reference cannot pack (bitpack.Pack stops at 4): checked through the decoder."""
