@@ -321,7 +321,7 @@ def main():
             "device_ms_per_step_events": round(float(np.mean(tot_ms)), 4),
             "setup_seconds": round(t_build, 1),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on a single-GPU run only
             res["cpu_baseline"] = cpu_baseline(buf, pf, args.cpu_seconds)
         if args.pcie:
             res["pcie_inclusive"] = pcie_inclusive(ctx, plan, pf, d_src, alg)

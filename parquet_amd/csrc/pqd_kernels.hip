@@ -524,9 +524,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
 // =====================================================================================
 // PLAIN BYTE_ARRAY chains.  A length prefix is cheap to parse and a wrong start dies fast (a random
 // length overshoots the page), so strings do not need the every-byte sweep of k_chain:
-//   k_str_exits   pass 1: lane i follows the chain that starts at byte i of the tile (i < E = 64)
-//                 through an LDS copy of the tile until it leaves the tile; the exit table gets where it
-//                 left and how many strings it passed.  Same table, same hop kernels as the level chains.
+//   k_str_exits   pass 1: follows the chain that starts at byte i of the tile (i < E = 64) through an LDS
+//                 copy of the tile until it leaves the tile; the exit table gets where it left and how
+//                 many strings it passed.  Same table, same hop kernels as the level chains.
 //   k_str_mark    pass 2: lane 0 walks the true chain from the tile's true entry and sets one bit per
 //                 string start; the wave then writes offsets[] (rank = prefix popcount) and the chars:
 //                 every byte of the tile from the true entry on is a length byte or a char, chars are
@@ -576,40 +576,116 @@ static __device__ __forceinline__ u32 str_len_at(const u32* s_tile, u32 rel) {
     return __builtin_amdgcn_alignbit(s_tile[d + 1], s_tile[d], (rel & 3) * 8);
 }
 
+// Pass 1 handles STR_TG tiles per wave.  Nearly every candidate start is not a string start and its chain
+// leaves the tile within a step or two (a random length overshoots the page), so a tile walked on its own
+// keeps two or three of its 64 lanes busy for ~85 steps.  Instead every tile's 64 candidates take STR_P1
+// steps (without leaving the tile's first 256-byte block, so no checkpoint is due yet), the chains still
+// inside their tile are packed into a queue, and the lanes walk the queue's chains to the end.
+constexpr u32 STR_TG = 8;
+constexpr u32 STR_P1 = 3;
 __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__ src_base, const Region* __restrict__ regions,
-                                                          const u32* __restrict__ tile_prefix, u32 n_regions,
+                                                          const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
                                                           ExitRec* __restrict__ exit_tbl, u32x4* __restrict__ str_cp) {
     static_assert(CH_E_STRINGS == CH_THREADS, "one lane per tabulated entry");
-    __shared__ __attribute__((aligned(16))) u32 s_tile[STR_LDS_WORDS];
+    static_assert(STR_TG <= 8 && CH_T <= 2048 && STR_P1 < 16, "queue entry: 3 bits tile, 6 entry, 11 offset, count above");
+    __shared__ __attribute__((aligned(16))) u32 s_tile[STR_TG * STR_LDS_WORDS];
     // checkpoints: the first position of the lane's chain inside each 256-byte block of the tile (tile
     // offset; 0xFFFF = none).  Pass 2 splits its walk of the true chain at them.
     __shared__ __attribute__((aligned(16))) unsigned short s_cp[CH_THREADS * STR_CP];
-    const u32 lane = threadIdx.x, tile = blockIdx.x;
-    const u32 ri = find_owner(tile_prefix, n_regions, tile);
-    const Region R = regions[ri];
-    const u32 L = R.len;
-    const u32 tb = (tile - tile_prefix[ri]) * CH_T;
-    const u32 lim = tb + CH_T < L ? tb + CH_T : L;
-    u32 w[8];
-    str_stage_tile(src_base + R.src_off, L, tb, lane, w, s_tile);
-    __syncthreads();
-    *(u32x4*)(s_cp + lane * STR_CP) = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    u32 q = tb + lane, cnt = 0, kprev = 0;
-    while (q < lim) {  // ERR_POS ends the loop too
-        const u32 rel = q - tb, k = rel / STR_CP_BYTES;
-        if (k != kprev) {  // first position of the chain inside 256-byte block k
-            s_cp[lane * STR_CP + k] = (unsigned short)rel;
-            kprev = k;
-        }
-        u32 nxt;
-        str_step_win(str_len_at(s_tile, rel), q, L, nxt);
-        cnt++;
-        q = nxt;
+    __shared__ u32 s_queue[STR_TG * CH_THREADS];
+    __shared__ u32 s_tb[STR_TG], s_len[STR_TG];
+    __shared__ u64 s_src[STR_TG];
+    const u32 lane = threadIdx.x, t0 = blockIdx.x * STR_TG;
+    const u32 nt = n_tiles - t0 < STR_TG ? n_tiles - t0 : STR_TG;
+    if (lane < nt) {
+        const u32 ri = find_owner(tile_prefix, n_regions, t0 + lane);
+        const Region R = regions[ri];
+        s_tb[lane] = (t0 + lane - tile_prefix[ri]) * CH_T;
+        s_len[lane] = R.len;
+        s_src[lane] = R.src_off;
     }
-    ExitRec x;
-    x.tgt = q; x.cnt = cnt; x.vals = 0;
-    exit_tbl[(u64)tile * CH_E_STRINGS + lane] = x;
-    str_cp[(u64)tile * CH_THREADS + lane] = *(const u32x4*)(s_cp + lane * STR_CP);  // own row: no barrier needed
+    __syncthreads();
+    bool whole = nt == STR_TG;  // every tile complete, lookahead included: all loads can be in flight at once
+    for (u32 t = 0; t < nt; t++) whole = whole && s_tb[t] + CH_T + 4 <= s_len[t];
+    if (whole) {
+        u32x4 a[STR_TG], b[STR_TG];
+#pragma unroll
+        for (u32 t = 0; t < STR_TG; t++) {
+            const u8* p = src_base + s_src[t] + s_tb[t] + lane * CH_SUB;
+            a[t] = *(const u32x4_u*)p;
+            b[t] = *(const u32x4_u*)(p + 16);
+        }
+        u32 ahead = 0;
+        if (lane < STR_TG) ahead = *(const u32_u*)(src_base + s_src[lane] + s_tb[lane] + CH_T);
+#pragma unroll
+        for (u32 t = 0; t < STR_TG; t++) {
+            *(u32x4*)(s_tile + t * STR_LDS_WORDS + lane * 8) = a[t];
+            *(u32x4*)(s_tile + t * STR_LDS_WORDS + lane * 8 + 4) = b[t];
+        }
+        if (lane < STR_TG) { s_tile[lane * STR_LDS_WORDS + CH_T / 4] = ahead; s_tile[lane * STR_LDS_WORDS + CH_T / 4 + 1] = 0; }
+    } else {
+        for (u32 t = 0; t < nt; t++) {
+            u32 w[8];
+            str_stage_tile(src_base + s_src[t], s_len[t], s_tb[t], lane, w, s_tile + t * STR_LDS_WORDS);
+        }
+    }
+    __syncthreads();
+    const u64 lt = (1ull << lane) - 1;
+    const u32x4 none = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    u32 qn = 0;
+    for (u32 t = 0; t < nt; t++) {
+        const u32 tb = s_tb[t], L = s_len[t];
+        const u32 lim = tb + CH_T < L ? tb + CH_T : L;
+        const u32 lim1 = tb + STR_CP_BYTES < lim ? tb + STR_CP_BYTES : lim;
+        const u32* tl = s_tile + t * STR_LDS_WORDS;
+        u32 q = tb + lane, cnt = 0;
+#pragma unroll
+        for (u32 k = 0; k < STR_P1; k++) {
+            const bool go = q < lim1;
+            u32 nxt;
+            str_step_win(str_len_at(tl, go ? q - tb : 0), go ? q : 0, L, nxt);
+            q = go ? nxt : q;
+            cnt += go;
+        }
+        const bool alive = q < lim;
+        const u64 bal = __ballot(alive);
+        if (alive) s_queue[qn + (u32)__popcll(bal & lt)] = t | (lane << 3) | ((q - tb) << 9) | (cnt << 20);
+        else {
+            ExitRec x;
+            x.tgt = q; x.cnt = cnt; x.vals = 0;
+            exit_tbl[(u64)(t0 + t) * CH_E_STRINGS + lane] = x;
+            str_cp[(u64)(t0 + t) * CH_THREADS + lane] = none;
+        }
+        qn += (u32)__popcll(bal);
+    }
+    __syncthreads();
+    for (u32 base = 0; base < qn; base += CH_THREADS) {
+        const bool have = base + lane < qn;
+        const u32 e = have ? s_queue[base + lane] : 0;
+        const u32 t = e & 7, cand = (e >> 3) & 63;
+        const u32 tb = s_tb[t], L = s_len[t];
+        const u32 lim = tb + CH_T < L ? tb + CH_T : L;
+        const u32* tl = s_tile + t * STR_LDS_WORDS;
+        *(u32x4*)(s_cp + lane * STR_CP) = none;
+        u32 q = have ? tb + ((e >> 9) & 2047) : ERR_POS, cnt = e >> 20, kprev = 0;
+        while (q < lim) {  // ERR_POS ends the loop too
+            const u32 rel = q - tb, k = rel / STR_CP_BYTES;
+            if (k != kprev) {  // first position of the chain inside 256-byte block k
+                s_cp[lane * STR_CP + k] = (unsigned short)rel;
+                kprev = k;
+            }
+            u32 nxt;
+            str_step_win(str_len_at(tl, rel), q, L, nxt);
+            cnt++;
+            q = nxt;
+        }
+        if (have) {
+            ExitRec x;
+            x.tgt = q; x.cnt = cnt; x.vals = 0;
+            exit_tbl[(u64)(t0 + t) * CH_E_STRINGS + cand] = x;
+            str_cp[(u64)(t0 + t) * CH_THREADS + cand] = *(const u32x4*)(s_cp + lane * STR_CP);  // own row: no barrier needed
+        }
+    }
 }
 
 __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ src_base, const Region* __restrict__ regions,
@@ -1818,8 +1894,8 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
     if (phase == 0) {
         if (a.n_tiles) {
             if constexpr (KIND == KIND_STRINGS)
-                hipLaunchKernelGGL(k_str_exits, dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix,
-                                   a.n_regions, a.exit_tbl, (u32x4*)a.str_cp);
+                hipLaunchKernelGGL(k_str_exits, dim3((a.n_tiles + STR_TG - 1) / STR_TG), dim3(CH_THREADS), 0, st, src, a.regions,
+                                   a.tile_prefix, a.n_regions, a.n_tiles, a.exit_tbl, (u32x4*)a.str_cp);
             else
                 hipLaunchKernelGGL((k_chain<KIND, false>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions,
                                    a.tile_prefix, a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn);
