@@ -581,7 +581,7 @@ static __device__ __forceinline__ u32 str_len_at(const u32* s_tile, u32 rel) {
 // keeps two or three of its 64 lanes busy for ~85 steps.  Instead every tile's 64 candidates take STR_P1
 // steps (without leaving the tile's first 256-byte block, so no checkpoint is due yet), the chains still
 // inside their tile are packed into a queue, and the lanes walk the queue's chains to the end.
-constexpr u32 STR_TG = 8;
+constexpr u32 STR_TG = 4;
 constexpr u32 STR_P1 = 3;
 __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                           const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
     __shared__ __attribute__((aligned(16))) u32 s_tile[STR_TG * STR_LDS_WORDS];
     // checkpoints: the first position of the lane's chain inside each 256-byte block of the tile (tile
     // offset; 0xFFFF = none).  Pass 2 splits its walk of the true chain at them.
-    __shared__ __attribute__((aligned(16))) unsigned short s_cp[CH_THREADS * STR_CP];
+    __shared__ __attribute__((aligned(16))) u32 s_cp[CH_THREADS * STR_CP];
     __shared__ u32 s_queue[STR_TG * CH_THREADS];
     __shared__ u32 s_tb[STR_TG], s_len[STR_TG];
     __shared__ u64 s_src[STR_TG];
@@ -632,27 +632,38 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
     __syncthreads();
     const u64 lt = (1ull << lane) - 1;
     const u32x4 none = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    u32 qn = 0;
-    for (u32 t = 0; t < nt; t++) {
-        const u32 tb = s_tb[t], L = s_len[t];
-        const u32 lim = tb + CH_T < L ? tb + CH_T : L;
-        const u32 lim1 = tb + STR_CP_BYTES < lim ? tb + STR_CP_BYTES : lim;
-        const u32* tl = s_tile + t * STR_LDS_WORDS;
-        u32 q = tb + lane, cnt = 0;
+    // the first steps of all tiles side by side: eight independent chains per lane hide the LDS latency
+    u32 q[STR_TG], cnt[STR_TG], tbs[STR_TG], lens[STR_TG], lims[STR_TG];
 #pragma unroll
-        for (u32 k = 0; k < STR_P1; k++) {
-            const bool go = q < lim1;
+    for (u32 t = 0; t < STR_TG; t++) {
+        tbs[t] = t < nt ? s_tb[t] : 0;
+        lens[t] = t < nt ? s_len[t] : 0;
+        lims[t] = tbs[t] + CH_T < lens[t] ? tbs[t] + CH_T : lens[t];
+        q[t] = t < nt ? tbs[t] + lane : ERR_POS;
+        cnt[t] = 0;
+    }
+#pragma unroll
+    for (u32 k = 0; k < STR_P1; k++) {
+#pragma unroll
+        for (u32 t = 0; t < STR_TG; t++) {
+            const u32 lim1 = tbs[t] + STR_CP_BYTES < lims[t] ? tbs[t] + STR_CP_BYTES : lims[t];
+            const bool go = q[t] < lim1;
             u32 nxt;
-            str_step_win(str_len_at(tl, go ? q - tb : 0), go ? q : 0, L, nxt);
-            q = go ? nxt : q;
-            cnt += go;
+            str_step_win(str_len_at(s_tile + t * STR_LDS_WORDS, go ? q[t] - tbs[t] : 0), go ? q[t] : 0, go ? lens[t] : 4, nxt);
+            q[t] = go ? nxt : q[t];
+            cnt[t] += go;
         }
-        const bool alive = q < lim;
+    }
+    u32 qn = 0;
+#pragma unroll
+    for (u32 t = 0; t < STR_TG; t++) {
+        if (t >= nt) break;
+        const bool alive = q[t] < lims[t];
         const u64 bal = __ballot(alive);
-        if (alive) s_queue[qn + (u32)__popcll(bal & lt)] = t | (lane << 3) | ((q - tb) << 9) | (cnt << 20);
+        if (alive) s_queue[qn + (u32)__popcll(bal & lt)] = t | (lane << 3) | ((q[t] - tbs[t]) << 9) | (cnt[t] << 20);
         else {
             ExitRec x;
-            x.tgt = q; x.cnt = cnt; x.vals = 0;
+            x.tgt = q[t]; x.cnt = cnt[t]; x.vals = 0;
             exit_tbl[(u64)(t0 + t) * CH_E_STRINGS + lane] = x;
             str_cp[(u64)(t0 + t) * CH_THREADS + lane] = none;
         }
@@ -666,24 +677,26 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
         const u32 tb = s_tb[t], L = s_len[t];
         const u32 lim = tb + CH_T < L ? tb + CH_T : L;
         const u32* tl = s_tile + t * STR_LDS_WORDS;
-        *(u32x4*)(s_cp + lane * STR_CP) = none;
-        u32 q = have ? tb + ((e >> 9) & 2047) : ERR_POS, cnt = e >> 20, kprev = 0;
-        while (q < lim) {  // ERR_POS ends the loop too
-            const u32 rel = q - tb, k = rel / STR_CP_BYTES;
-            if (k != kprev) {  // first position of the chain inside 256-byte block k
-                s_cp[lane * STR_CP + k] = (unsigned short)rel;
-                kprev = k;
-            }
+        u32* cp = s_cp + lane * STR_CP;
+        *(u32x4*)cp = none;
+        *(u32x4*)(cp + 4) = none;
+        u32 qq = have ? tb + ((e >> 9) & 2047) : ERR_POS, c = e >> 20;
+        while (qq < lim) {  // ERR_POS ends the loop too
+            const u32 rel = qq - tb;
+            atomicMin(cp + rel / STR_CP_BYTES, rel);  // positions only grow: the first one of every block stays
             u32 nxt;
-            str_step_win(str_len_at(tl, rel), q, L, nxt);
-            cnt++;
-            q = nxt;
+            str_step_win(str_len_at(tl, rel), qq, L, nxt);
+            c++;
+            qq = nxt;
         }
         if (have) {
             ExitRec x;
-            x.tgt = q; x.cnt = cnt; x.vals = 0;
+            x.tgt = qq; x.cnt = c; x.vals = 0;
             exit_tbl[(u64)(t0 + t) * CH_E_STRINGS + cand] = x;
-            str_cp[(u64)(t0 + t) * CH_THREADS + cand] = *(const u32x4*)(s_cp + lane * STR_CP);  // own row: no barrier needed
+            // own row: no barrier needed.  Slot 0 is not a checkpoint (the walk of block 0 starts at the entry).
+            const u32x4 lo = *(const u32x4*)cp, hi = *(const u32x4*)(cp + 4);
+            str_cp[(u64)(t0 + t) * CH_THREADS + cand] =
+                u32x4{0xFFFFu | (lo.y << 16), (lo.z & 0xFFFFu) | (lo.w << 16), (hi.x & 0xFFFFu) | (hi.y << 16), (hi.z & 0xFFFFu) | (hi.w << 16)};
         }
     }
 }
