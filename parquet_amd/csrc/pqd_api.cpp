@@ -58,6 +58,7 @@ struct pqd_plan {
     std::vector<Seg> segs;
     std::vector<u32> seg_blk_prefix;
     std::vector<u32> bool_pages, btile_prefix, row_chunks, rtile_prefix;
+    std::vector<u32> ltile_region, stile_region;  // region of every chain tile
     std::vector<OutPtrs> outs;
     std::vector<int> chunk_width;
 
@@ -410,6 +411,10 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         pl->otile_region.insert(pl->otile_region.end(), pl->lotile_prefix[r + 1] - pl->lotile_prefix[r], (u32)r);
     pl->otile_region.push_back(ERR_POS);  // spare entry: the tile after the last belongs to no region
     pl->n_stiles_chain = pl->stile_chain_prefix.back();
+    for (size_t r = 0; r < pl->lregions.size(); r++)
+        pl->ltile_region.insert(pl->ltile_region.end(), pl->ltile_prefix[r + 1] - pl->ltile_prefix[r], (u32)r);
+    for (size_t r = 0; r < pl->sregions.size(); r++)
+        pl->stile_region.insert(pl->stile_region.end(), pl->stile_chain_prefix[r + 1] - pl->stile_chain_prefix[r], (u32)r);
     pl->n_btiles = pl->btile_prefix.back();
     pl->n_rtiles = pl->rtile_prefix.back();
 
@@ -422,6 +427,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_lotp = ap.take(pl->lotile_prefix.size() * 4);
     const size_t o_otr = ap.take(pl->otile_region.size() * 4);
     const size_t o_sctp = ap.take(pl->stile_chain_prefix.size() * 4);
+    const size_t o_ltr = ap.take(pl->ltile_region.size() * 4), o_str = ap.take(pl->stile_region.size() * 4);
     const size_t o_lgp = ap.take(pl->lgroup_prefix.size() * 4);
     const size_t o_sgp = ap.take(pl->sgroup_prefix.size() * 4);
     const size_t o_ssp = ap.take(pl->ssuper_prefix.size() * 4);
@@ -542,6 +548,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->schain = ChainArgs{pl->d_sregions, pl->d_stile_chain_prefix, pl->d_sgroup_prefix, (u32)pl->sregions.size(), pl->n_stiles_chain,
                            n_sgroups, pl->d_sexit, pl->d_sgexit, pl->d_stile_entry, pl->d_sgroup_entry, pl->d_stotals, A + o_scp,
                            (u32*)(A + o_ssp), n_ssupers, (ExitRec*)(A + o_ssexit), (TileEntry*)(A + o_sse)};
+    pl->lchain.tile_region = (u32*)(A + o_ltr);
+    pl->schain.tile_region = (u32*)(A + o_str);
 
     int rc;
     if ((rc = upload(ctx, pl->d_chunks, pl->chunks))) return rc;
@@ -552,6 +560,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if ((rc = upload(ctx, pl->d_lotile_prefix, pl->lotile_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_otile_region, pl->otile_region))) return rc;
     if ((rc = upload(ctx, pl->d_stile_chain_prefix, pl->stile_chain_prefix))) return rc;
+    if ((rc = upload(ctx, (u32*)(A + o_ltr), pl->ltile_region))) return rc;
+    if ((rc = upload(ctx, (u32*)(A + o_str), pl->stile_region))) return rc;
     if ((rc = upload(ctx, pl->d_lgroup_prefix, pl->lgroup_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_sgroup_prefix, pl->sgroup_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_ssuper_prefix, pl->ssuper_prefix))) return rc;

@@ -121,6 +121,7 @@ struct ChainArgs {
     u32 n_supers;
     ExitRec* sexit;           // n_supers * E
     TileEntry* super_entry;   // n_supers  (reset to 0xFF before every run)
+    const u32* tile_region;   // n_tiles: the region of every tile (optional; null: the kernels search tile_prefix)
 };
 hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs& a, RunRec* run_tbl, u32* otile_first_run,
                         const PageDyn* page_dyn, int* status, int phase);

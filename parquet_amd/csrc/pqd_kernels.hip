@@ -265,7 +265,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
                                                       const u32* __restrict__ tile_prefix, u32 n_regions,
                                                       ExitRec* __restrict__ exit_tbl, const TileEntry* __restrict__ tile_entry,
                                                       RunRec* __restrict__ run_tbl, u32* __restrict__ otile_first_run,
-                                                      const PageDyn* __restrict__ page_dyn) {
+                                                      const PageDyn* __restrict__ page_dyn, const u32* __restrict__ tile_region) {
     static_assert(KIND != KIND_STRINGS, "strings have their own chain kernels");
     constexpr u32 E = CH_E_LEVELS;
     constexpr u32 OTK = KIND == KIND_SNAPPY ? SN_T : OT;  // output bytes per tile of the kernel that consumes the records
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
 
     const u32 lane = threadIdx.x;
     const u32 tile = blockIdx.x;
-    const u32 ri = find_owner(tile_prefix, n_regions, tile);
+    const u32 ri = tile_region ? tile_region[tile] : find_owner(tile_prefix, n_regions, tile);
     const Region R = regions[ri];
     const u32 L = R.len;
     const u32 tb = (tile - tile_prefix[ri]) * CH_T;  // region position of the tile start
@@ -585,7 +585,8 @@ constexpr u32 STR_TG = 4;
 constexpr u32 STR_P1 = 3;
 __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                           const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
-                                                          ExitRec* __restrict__ exit_tbl, u32x4* __restrict__ str_cp) {
+                                                          ExitRec* __restrict__ exit_tbl, u32x4* __restrict__ str_cp,
+                                                          const u32* __restrict__ tile_region) {
     static_assert(CH_E_STRINGS == CH_THREADS, "one lane per tabulated entry");
     static_assert(STR_TG <= 8 && CH_T <= 2048 && STR_P1 < 16, "queue entry: 3 bits tile, 6 entry, 11 offset, count above");
     __shared__ __attribute__((aligned(16))) u32 s_tile[STR_TG * STR_LDS_WORDS];
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
     const u32 lane = threadIdx.x, t0 = blockIdx.x * STR_TG;
     const u32 nt = n_tiles - t0 < STR_TG ? n_tiles - t0 : STR_TG;
     if (lane < nt) {
-        const u32 ri = find_owner(tile_prefix, n_regions, t0 + lane);
+        const u32 ri = tile_region ? tile_region[t0 + lane] : find_owner(tile_prefix, n_regions, t0 + lane);
         const Region R = regions[ri];
         s_tb[lane] = (t0 + lane - tile_prefix[ri]) * CH_T;
         s_len[lane] = R.len;
@@ -705,14 +706,14 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
                                                          const u32* __restrict__ tile_prefix, u32 n_regions,
                                                          const TileEntry* __restrict__ tile_entry,
                                                          const u32x4* __restrict__ str_cp,
-                                                         const PageDyn* __restrict__ page_dyn) {
+                                                         const PageDyn* __restrict__ page_dyn, const u32* __restrict__ tile_region) {
     __shared__ __attribute__((aligned(16))) u32 s_tile[STR_LDS_WORDS];
     __shared__ __attribute__((aligned(16))) u8 s_stage[CH_T + 16];
     __shared__ u32 s_bits[64], s_last[2];
     const u32 lane = threadIdx.x, tile = blockIdx.x;
     const TileEntry ent = tile_entry[tile];
     if (ent.pos == ERR_POS) return;  // no string starts in this tile
-    const u32 ri = find_owner(tile_prefix, n_regions, tile);
+    const u32 ri = tile_region ? tile_region[tile] : find_owner(tile_prefix, n_regions, tile);
     const Region R = regions[ri];
     const u32 L = R.len;
     const u32 tb = (tile - tile_prefix[ri]) * CH_T, te = tb + CH_T;
@@ -1908,10 +1909,11 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
         if (a.n_tiles) {
             if constexpr (KIND == KIND_STRINGS)
                 hipLaunchKernelGGL(k_str_exits, dim3((a.n_tiles + STR_TG - 1) / STR_TG), dim3(CH_THREADS), 0, st, src, a.regions,
-                                   a.tile_prefix, a.n_regions, a.n_tiles, a.exit_tbl, (u32x4*)a.str_cp);
+                                   a.tile_prefix, a.n_regions, a.n_tiles, a.exit_tbl, (u32x4*)a.str_cp, a.tile_region);
             else
                 hipLaunchKernelGGL((k_chain<KIND, false>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions,
-                                   a.tile_prefix, a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn);
+                                   a.tile_prefix, a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn,
+                                   a.tile_region);
             LAUNCH_CHECK();
             hipLaunchKernelGGL((k_chain_groups<KIND>), dim3(a.n_groups * (E / 64)), dim3(64), 0, st, src, a.regions,
                                a.group_prefix, a.n_regions, a.exit_tbl, a.gexit);
@@ -1941,10 +1943,10 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
     } else if (a.n_tiles) {
         if constexpr (KIND == KIND_STRINGS)
             hipLaunchKernelGGL(k_str_mark, dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix, a.n_regions,
-                               a.tile_entry, (const u32x4*)a.str_cp, page_dyn);
+                               a.tile_entry, (const u32x4*)a.str_cp, page_dyn, a.tile_region);
         else
             hipLaunchKernelGGL((k_chain<KIND, true>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix,
-                               a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn);
+                               a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn, a.tile_region);
         LAUNCH_CHECK();
     }
     return hipSuccess;
