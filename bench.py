@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--pcie", action="store_true", help="also measure the rate including H2D and D2H copies")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even for one rank (rehearses the collective path on a one-GPU box)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo lets several ranks share one GPU (rehearsal of the N>1 path on a 1-GPU box)")
     return ap.parse_args()
@@ -183,8 +185,12 @@ def main():
     if args.dist_backend == "gloo":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -219,7 +225,7 @@ def main():
     rows_all = torch.zeros(world, dtype=torch.int64, device=coll_dev)
 
     def step():
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(rows_all, rows_local)  # per-shard row counts → global row offsets
         plan.run(d_src)
 
@@ -241,7 +247,7 @@ def main():
         assert ok and o == first_vals.size, "decoded values differ from the page payloads"
 
     steps = args.steps
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -250,7 +256,7 @@ def main():
     plan.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -259,7 +265,7 @@ def main():
     bytes_in, bytes_out, copy_bytes = plan.bytes()
     alg = bytes_in + bytes_out
     alg_t = torch.tensor([alg], dtype=torch.int64, device=coll_dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(alg_t)
     total_alg = int(alg_t.item())
 
@@ -330,7 +336,7 @@ def main():
     plan.close()
     N.decode.pqd_device_free(ctx.handle, d_src)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
