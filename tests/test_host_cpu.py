@@ -25,6 +25,37 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(N.DECODE_SYMBOLS), declared ^ set(N.DECODE_SYMBOLS)
 
 
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """The boundary is a C ABI: the header compiles as C99 with no C++ or torch types in it, and a C program
+    linked against the library walks a file with the host-only entry points (no device needed)."""
+    import subprocess
+    buf = bytes(_flat_file(np.random.default_rng(11), n=500, page=100, group=250)[2])
+    (tmp_path / "f.parquet").write_bytes(buf)
+    (tmp_path / "t.c").write_text(r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include "pqdecode.h"
+int main(int argc, char** argv) {
+    FILE* fp = fopen(argv[1], "rb");
+    if (!fp) return 2;
+    fseek(fp, 0, SEEK_END); long n = ftell(fp); fseek(fp, 0, SEEK_SET);
+    unsigned char* b = malloc((size_t)n);
+    if (fread(b, 1, (size_t)n, fp) != (size_t)n) return 3;
+    pqd_file* f = NULL; char err[256];
+    if (pqd_file_open(b, (size_t)n, &f, err, sizeof err) != 0) { puts(err); return 4; }
+    printf("%lld %lld\n", (long long)pqd_file_num_rows(f), (long long)pqd_file_num_pages(f));
+    pqd_file_close(f);
+    return 0;
+}
+''')
+    lib = os.path.join(ROOT, "parquet_amd", "lib")
+    exe = str(tmp_path / "t")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(tmp_path / "t.c"),
+                    "-o", exe, "-L", lib, "-lpqdecode", "-Wl,-rpath," + lib], check=True)
+    out = subprocess.run([exe, str(tmp_path / "f.parquet")], check=True, capture_output=True, text=True).stdout.split()
+    assert out[0] == "500" and int(out[1]) == 8 * 2 * 3  # 8 columns, 2 row groups of 250 rows, 3 pages of <= 100 rows each
+
+
 def test_no_device_means_loud_failure():
     import torch
     if torch.cuda.is_available():
