@@ -595,8 +595,12 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
 
     // PLAIN fixed-width values: independent of the levels (the reference reads the concatenated
     // values regions as one stream).  The gather is HBM-bound and the level / string chains are
-    // instruction-bound, so when both exist the gather runs beside them on a second stream.
-    const bool side = ctx->overlap && pl->n_copy_blocks && (n_lreg || n_sreg);
+    // instruction-bound, so when both exist the gather runs beside them on a second stream.  The first
+    // pass over the strings (exit tables, hops, totals) needs nothing from the levels either and the level
+    // chain of a string column is a few thousand tiles that leave most of the device idle, so it goes to
+    // the second stream too; only the marking pass waits for the value counts.
+    const bool str_early = ctx->overlap && n_lreg && n_sreg;
+    const bool side = ctx->overlap && ((pl->n_copy_blocks && (n_lreg || n_sreg)) || str_early);
     hipStream_t cst = side ? ctx->stream2 : st;
     if (side) {
         HIP_TRY(ctx, hipEventRecord(pl->ev_fork, st));
@@ -605,7 +609,9 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     if (ev_c0) HIP_TRY(ctx, hipEventRecord(ev_c0, cst));
     HIP_TRY(ctx, launch_copy(cst, src, pl->d_segs, pl->d_seg_blk_prefix, (u32)pl->segs.size(), pl->n_copy_blocks, ctx->copy_grid));
     if (ev_c1) HIP_TRY(ctx, hipEventRecord(ev_c1, cst));
-    else if (side) HIP_TRY(ctx, hipEventRecord(pl->ev_join, cst));
+    if (str_early)
+        HIP_TRY(ctx, launch_chain(cst, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 0));
+    if (side) HIP_TRY(ctx, hipEventRecord(pl->ev_join, cst));
 
     // levels
     if (n_lreg) {
@@ -618,13 +624,14 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, (u32)pl->bool_pages.size(), pl->n_btiles,
                               pl->d_chunks, pl->d_page_dyn));
     if (n_sreg) {
-        HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 0));
+        if (str_early) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join, 0));
+        else HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 0));
         HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 1));
         HIP_TRY(ctx, launch_str_check(st, pl->d_pages, pl->d_chunks, pl->d_page_dyn, pl->d_sregions, n_sreg, pl->d_stotals, pl->d_status));
     }
     HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
                              pl->d_row_tiles, pl->d_chunk_dyn));
-    if (side) HIP_TRY(ctx, hipStreamWaitEvent(st, ev_c1 ? ev_c1 : pl->ev_join, 0));
+    if (side) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join, 0));
     return PQD_OK;
 }
 
