@@ -711,10 +711,16 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
     __shared__ __attribute__((aligned(16))) u8 s_stage[CH_T + 16];
     __shared__ u32 s_bits[64], s_last[2];
     const u32 lane = threadIdx.x, tile = blockIdx.x;
+    // loads that do not depend on each other are issued together: entry and region index, then the region,
+    // the entry's checkpoint row and the page's offsets
     const TileEntry ent = tile_entry[tile];
-    if (ent.pos == ERR_POS) return;  // no string starts in this tile
     const u32 ri = tile_region ? tile_region[tile] : find_owner(tile_prefix, n_regions, tile);
+    if (ent.pos == ERR_POS) return;  // no string starts in this tile
+    const u32 e = ent.pos & (CH_T - 1);  // tiles start at multiples of CH_T of the region
+    unsigned short cp = 0xFFFF;
+    if (lane < STR_CP && e < CH_E_STRINGS) cp = ((const unsigned short*)(str_cp + (u64)tile * CH_THREADS + e))[lane];
     const Region R = regions[ri];
+    const PageDyn pd = page_dyn[R.page];
     const u32 L = R.len;
     const u32 tb = (tile - tile_prefix[ri]) * CH_T, te = tb + CH_T;
     const u32 lim = te < L ? te : L;
@@ -728,11 +734,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
     // its first position inside each 256-byte block of the tile; lane j walks block j.
     // An entry beyond the tabulated window (a long string ends here) is walked by lane 0 alone.
     if (lane < STR_CP) {
-        const u32 e = ent.pos - tb;
         u32 q = ERR_POS, end = lim;
         if (e >= CH_E_STRINGS) { if (lane == 0) q = ent.pos; }
         else {
-            const unsigned short cp = ((const unsigned short*)(str_cp + (u64)tile * CH_THREADS + e))[lane];
             if (lane == 0) q = ent.pos;
             else if (cp != 0xFFFF) q = tb + cp;
             const u32 b = tb + (lane + 1) * STR_CP_BYTES;
@@ -774,7 +778,6 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
     const u32 total = __shfl(incl, 63);
     const u32 n_chars = total & 0xFFFF;
     const u32 pc = (incl - mine) & 0xFFFF, ps = (incl - mine) >> 16;
-    const PageDyn pd = page_dyn[R.page];
     const u32 cbase = (u32)pd.char_off;  // offsets are int32: a chunk holds less than 2^31 chars
     // offsets: string `rank` of the page starts at q, its chars at q + 4; every earlier string of the page
     // contributed 4 length bytes.  A page never holds more values than levels.
