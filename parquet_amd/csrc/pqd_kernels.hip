@@ -702,119 +702,171 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
     }
 }
 
+// Pass 2 is a chain of dependent steps per tile (entry -> region -> tile bytes -> walk -> scan -> stores), so a
+// wave takes STR_MG tiles and runs every step for all of them before it waits; the walks of all tiles share
+// the same dependent LDS round trips (8 lanes per tile).  The LDS image of a tile is needed only for the walk
+// and gives its place to the tile's compaction buffer afterwards.
+constexpr u32 STR_MG = 2;
+static_assert(CH_T + 16 <= STR_LDS_WORDS * 4, "the compaction buffer reuses the tile image");
 __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ src_base, const Region* __restrict__ regions,
-                                                         const u32* __restrict__ tile_prefix, u32 n_regions,
+                                                         const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
                                                          const TileEntry* __restrict__ tile_entry,
                                                          const u32x4* __restrict__ str_cp,
                                                          const PageDyn* __restrict__ page_dyn, const u32* __restrict__ tile_region) {
-    __shared__ __attribute__((aligned(16))) u32 s_tile[STR_LDS_WORDS];
-    __shared__ __attribute__((aligned(16))) u8 s_stage[CH_T + 16];
-    __shared__ u32 s_bits[64], s_last[2];
-    const u32 lane = threadIdx.x, tile = blockIdx.x;
-    // loads that do not depend on each other are issued together: entry and region index, then the region,
-    // the entry's checkpoint row and the page's offsets
-    const TileEntry ent = tile_entry[tile];
-    const u32 ri = tile_region ? tile_region[tile] : find_owner(tile_prefix, n_regions, tile);
-    if (ent.pos == ERR_POS) return;  // no string starts in this tile
-    const u32 e = ent.pos & (CH_T - 1);  // tiles start at multiples of CH_T of the region
+    __shared__ __attribute__((aligned(16))) u32 s_buf[STR_MG][STR_LDS_WORDS];
+    __shared__ u32 s_bits[STR_MG][64], s_last[STR_MG][2];
+    const u32 lane = threadIdx.x, t0 = blockIdx.x * STR_MG;
+    // loads that do not depend on each other are issued together: entries and region indices, then the regions,
+    // the entries' checkpoint rows and the pages' offsets
+    u32 epos[STR_MG], ecnt[STR_MG], ri[STR_MG];
+    bool on[STR_MG];
+#pragma unroll
+    for (u32 t = 0; t < STR_MG; t++) {
+        const bool in = t0 + t < n_tiles;
+        const u32 tile = in ? t0 + t : t0;
+        const TileEntry ent = tile_entry[tile];
+        ri[t] = tile_region ? tile_region[tile] : find_owner(tile_prefix, n_regions, tile);
+        epos[t] = ent.pos; ecnt[t] = ent.cnt;
+        on[t] = in && ent.pos != ERR_POS;  // ERR_POS: no string starts in this tile
+    }
+    bool any = false;
+#pragma unroll
+    for (u32 t = 0; t < STR_MG; t++) any = any || on[t];
+    if (!any) return;
+    // walker lanes: lane l < 8 * STR_MG serves block l % 8 of tile l / 8
+    const u32 wt = lane / STR_CP, wj = lane % STR_CP;
+    u32 w_epos = ERR_POS, w_tile = t0;
+#pragma unroll
+    for (u32 t = 0; t < STR_MG; t++)
+        if (wt == t && on[t]) { w_epos = epos[t]; w_tile = t0 + t; }
+    const u32 w_e = w_epos & (CH_T - 1);  // tiles start at multiples of CH_T of the region
     unsigned short cp = 0xFFFF;
-    if (lane < STR_CP && e < CH_E_STRINGS) cp = ((const unsigned short*)(str_cp + (u64)tile * CH_THREADS + e))[lane];
-    const Region R = regions[ri];
-    const PageDyn pd = page_dyn[R.page];
-    const u32 L = R.len;
-    const u32 tb = (tile - tile_prefix[ri]) * CH_T, te = tb + CH_T;
-    const u32 lim = te < L ? te : L;
-    const u8* rsrc = src_base + R.src_off;
-    const u32 sub_lo = tb + lane * CH_SUB, sub_hi = sub_lo + CH_SUB;
-    u32 w[8];
-    str_stage_tile(rsrc, L, tb, lane, w, s_tile);
-    s_bits[lane] = 0;
+    if (w_epos != ERR_POS && w_e < CH_E_STRINGS) cp = ((const unsigned short*)(str_cp + (u64)w_tile * CH_THREADS + w_e))[wj];
+    Region R[STR_MG];
+    PageDyn pd[STR_MG];
+    u32 tb[STR_MG], lim[STR_MG];
+    u32 w[STR_MG][8];
+#pragma unroll
+    for (u32 t = 0; t < STR_MG; t++) {
+        R[t] = regions[ri[t]];
+        pd[t] = page_dyn[R[t].page];
+    }
+#pragma unroll
+    for (u32 t = 0; t < STR_MG; t++) {
+        const u32 tile = on[t] ? t0 + t : t0;
+        tb[t] = (tile - tile_prefix[ri[t]]) * CH_T;
+        lim[t] = tb[t] + CH_T < R[t].len ? tb[t] + CH_T : R[t].len;
+        if (on[t]) str_stage_tile(src_base + R[t].src_off, R[t].len, tb[t], lane, w[t], s_buf[t]);
+        s_bits[t][lane] = 0;
+    }
     __syncthreads();
-    // The true chain is walked by up to 8 lanes at once: pass 1 left, for the chain of every tabulated entry,
-    // its first position inside each 256-byte block of the tile; lane j walks block j.
-    // An entry beyond the tabulated window (a long string ends here) is walked by lane 0 alone.
-    if (lane < STR_CP) {
-        u32 q = ERR_POS, end = lim;
-        if (e >= CH_E_STRINGS) { if (lane == 0) q = ent.pos; }
+    // The true chain of a tile is walked by up to 8 lanes at once: pass 1 left, for the chain of every tabulated
+    // entry, its first position inside each 256-byte block of the tile; walker j takes block j.
+    // An entry beyond the tabulated window (a long string ends here) is walked by walker 0 alone.
+    if (w_epos != ERR_POS) {
+        u32 w_tb = 0, w_lim = 0, w_len = 0;
+#pragma unroll
+        for (u32 t = 0; t < STR_MG; t++)
+            if (wt == t) { w_tb = tb[t]; w_lim = lim[t]; w_len = R[t].len; }
+        const u32* tl = s_buf[wt];
+        u32* bits = s_bits[wt];
+        u32 q = ERR_POS, end = w_lim;
+        if (w_e >= CH_E_STRINGS) { if (wj == 0) q = w_epos; }
         else {
-            if (lane == 0) q = ent.pos;
-            else if (cp != 0xFFFF) q = tb + cp;
-            const u32 b = tb + (lane + 1) * STR_CP_BYTES;
-            end = b < lim ? b : lim;
+            if (wj == 0) q = w_epos;
+            else if (cp != 0xFFFF) q = w_tb + cp;
+            const u32 b = w_tb + (wj + 1) * STR_CP_BYTES;
+            end = b < w_lim ? b : w_lim;
         }
         u32 last_q = q, last_nxt = ERR_POS;
         bool walked = false;
         while (q < end) {
-            const u32 rel = q - tb;
-            atomicOr(&s_bits[rel >> 5], 1u << (rel & 31));
+            const u32 rel = q - w_tb;
+            atomicOr(&bits[rel >> 5], 1u << (rel & 31));
             u32 nxt;
-            str_step_win(str_len_at(s_tile, rel), q, L, nxt);
+            str_step_win(str_len_at(tl, rel), q, w_len, nxt);
             last_q = q;
             last_nxt = nxt;
             q = nxt;
             walked = true;
         }
-        // the lane whose walk left the tile (or hit a bad length) holds the tile's last string
-        if (walked && q >= lim) { s_last[0] = last_q; s_last[1] = last_nxt; }
+        // the walker that left the tile (or hit a bad length) holds the tile's last string
+        if (walked && q >= w_lim) { s_last[wt][0] = last_q; s_last[wt][1] = last_nxt; }
     }
     __syncthreads();
-    const u32 smask = s_bits[lane];  // true string starts of my sub-tile
-    u32 prev = __shfl_up(smask, 1);  // every lane takes part: a masked-off lane would hand its neighbour 0
-    if (lane == 0) prev = 0;
-    const u32 lenmask = smask | (smask << 1) | (smask << 2) | (smask << 3) | ((prev >> 29) & 1) | (((prev >> 30) & 1) * 3) |
-                        (((prev >> 31) & 1) * 7);
-    const u32 k_lo = ent.pos <= sub_lo ? 0 : ent.pos >= sub_hi ? 32 : ent.pos - sub_lo;
-    const u32 k_hi = lim >= sub_hi ? 32 : lim <= sub_lo ? 0 : lim - sub_lo;
-    u32 own = k_lo >= 32 ? 0 : 0xFFFFFFFFu << k_lo;
-    if (k_hi < 32) own &= (1u << k_hi) - 1;
-    const u32 charmask = own & ~lenmask;
-    // one scan for both counts: chars in the low half, starts in the high half (each <= 2048)
-    const u32 mine = __popc(charmask) | (__popc(smask) << 16);
-    u32 incl = mine;
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 t = __shfl_up(incl, d);
-        if (lane >= (u32)d) incl += t;
-    }
-    const u32 total = __shfl(incl, 63);
-    const u32 n_chars = total & 0xFFFF;
-    const u32 pc = (incl - mine) & 0xFFFF, ps = (incl - mine) >> 16;
-    const u32 cbase = (u32)pd.char_off;  // offsets are int32: a chunk holds less than 2^31 chars
-    // offsets: string `rank` of the page starts at q, its chars at q + 4; every earlier string of the page
-    // contributed 4 length bytes.  A page never holds more values than levels.
-    {
-        int32_t* const offs = (int32_t*)R.out + pd.val_off;
-        const u32 n_out = (u32)R.n_out;
-        u32 m = smask, rank = ent.cnt + ps;
-        while (m) {
-            const u32 k = __ffs(m) - 1;
-            m &= m - 1;
-            if (rank < n_out) offs[rank] = (int32_t)(cbase + (sub_lo + k) - 4u * rank);
-            rank++;
-        }
-    }
-    // chars: char byte number i of the tile goes to chars[g0 + i]
-    const u32 g0 = cbase + ent.pos - 4u * ent.cnt;
-    u8* const cdst = R.out2 + g0;
-    const u32 pad = (u32)((uintptr_t)cdst & 15);
+    u32 n_chars[STR_MG], pad[STR_MG];
+    u8* cdst[STR_MG];
 #pragma unroll
-    for (int k = 0; k < (int)CH_SUB; k++)
-        if ((charmask >> k) & 1) s_stage[pad + pc + __popc(charmask & ((1u << k) - 1))] = (u8)(w[k >> 2] >> (8 * (k & 3)));
-    __syncthreads();
-    const u32 n_stg = pad + n_chars;
-    for (u32 c0 = lane * 16; c0 < n_stg; c0 += 64 * 16) {
-        if (c0 >= pad && c0 + 16 <= n_stg) *(u32x4*)(cdst - pad + c0) = *(const u32x4*)(s_stage + c0);
-        else for (u32 b = c0 < pad ? pad : c0; b < c0 + 16 && b < n_stg; b++) cdst[b - pad] = s_stage[b];
+    for (u32 t = 0; t < STR_MG; t++) {
+        n_chars[t] = 0; pad[t] = 0; cdst[t] = nullptr;
+        if (!on[t]) continue;
+        const u32 sub_lo = tb[t] + lane * CH_SUB, sub_hi = sub_lo + CH_SUB;
+        const u32 smask = s_bits[t][lane];  // true string starts of my sub-tile
+        u32 prev = __shfl_up(smask, 1);     // every lane takes part: a masked-off lane would hand its neighbour 0
+        if (lane == 0) prev = 0;
+        const u32 lenmask = smask | (smask << 1) | (smask << 2) | (smask << 3) | ((prev >> 29) & 1) | (((prev >> 30) & 1) * 3) |
+                            (((prev >> 31) & 1) * 7);
+        const u32 k_lo = epos[t] <= sub_lo ? 0 : epos[t] >= sub_hi ? 32 : epos[t] - sub_lo;
+        const u32 k_hi = lim[t] >= sub_hi ? 32 : lim[t] <= sub_lo ? 0 : lim[t] - sub_lo;
+        u32 own = k_lo >= 32 ? 0 : 0xFFFFFFFFu << k_lo;
+        if (k_hi < 32) own &= (1u << k_hi) - 1;
+        const u32 charmask = own & ~lenmask;
+        // one scan for both counts: chars in the low half, starts in the high half (each <= 2048)
+        const u32 mine = __popc(charmask) | (__popc(smask) << 16);
+        u32 incl = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 x = __shfl_up(incl, d);
+            if (lane >= (u32)d) incl += x;
+        }
+        const u32 total = __shfl(incl, 63);
+        n_chars[t] = total & 0xFFFF;
+        const u32 pc = (incl - mine) & 0xFFFF, ps = (incl - mine) >> 16;
+        const u32 cbase = (u32)pd[t].char_off;  // offsets are int32: a chunk holds less than 2^31 chars
+        // offsets: string `rank` of the page starts at q, its chars at q + 4; every earlier string of the page
+        // contributed 4 length bytes.  A page never holds more values than levels.
+        {
+            int32_t* const offs = (int32_t*)R[t].out + pd[t].val_off;
+            const u32 n_out = (u32)R[t].n_out;
+            u32 m = smask, rank = ecnt[t] + ps;
+            while (m) {
+                const u32 k = __ffs(m) - 1;
+                m &= m - 1;
+                if (rank < n_out) offs[rank] = (int32_t)(cbase + (sub_lo + k) - 4u * rank);
+                rank++;
+            }
+        }
+        // chars: char byte number i of the tile goes to chars[g0 + i]
+        const u32 g0 = cbase + epos[t] - 4u * ecnt[t];
+        cdst[t] = R[t].out2 + g0;
+        pad[t] = (u32)((uintptr_t)cdst[t] & 15);
+        u8* const stage = (u8*)s_buf[t];  // the walk is over: the tile image is dead
+#pragma unroll
+        for (int k = 0; k < (int)CH_SUB; k++)
+            if ((charmask >> k) & 1) stage[pad[t] + pc + __popc(charmask & ((1u << k) - 1))] = (u8)(w[t][k >> 2] >> (8 * (k & 3)));
     }
-    // the last string of the tile may run past the tile: its remaining chars follow directly
-    const u32 lq = s_last[0], ln = s_last[1];
-    if (ln != ERR_POS && ln > lim) {
-        const u32 s_lo = lq + 4 > lim ? lq + 4 : lim;
-        const u8* sp = rsrc + s_lo;
-        u8* dp = cdst + n_chars;
-        const u32 n = ln - s_lo;
-        for (u32 c0 = lane * 16; c0 < n; c0 += 64 * 16) {
-            if (c0 + 16 <= n) *(u32x4_u*)(dp + c0) = *(const u32x4_u*)(sp + c0);
-            else for (u32 b = c0; b < n; b++) dp[b] = sp[b];
+    __syncthreads();
+#pragma unroll
+    for (u32 t = 0; t < STR_MG; t++) {
+        if (!on[t]) continue;
+        const u8* const stage = (const u8*)s_buf[t];
+        u8* const cd = cdst[t];
+        const u32 pd0 = pad[t], n_stg = pd0 + n_chars[t];
+        // aligned 16-byte stores between the first and the last 16-byte boundary; the up to 15 bytes on either
+        // side go one per lane (never a serial byte loop: every byte would cost a memory round trip)
+        const u32 head_end = ((pd0 + 15) & ~15u) < n_stg ? ((pd0 + 15) & ~15u) : n_stg;
+        const u32 tail_lo = (n_stg & ~15u) > head_end ? (n_stg & ~15u) : head_end;
+        for (u32 c0 = head_end + lane * 16; c0 < tail_lo; c0 += 64 * 16) *(u32x4*)(cd - pd0 + c0) = *(const u32x4*)(stage + c0);
+        if (lane < 16) { if (pd0 + lane < head_end) cd[lane] = stage[pd0 + lane]; }
+        else if (lane < 32) { const u32 b = tail_lo + lane - 16; if (b < n_stg) cd[b - pd0] = stage[b]; }
+        // the last string of the tile may run past the tile: its remaining chars follow directly
+        const u32 lq = s_last[t][0], ln = s_last[t][1];
+        if (ln != ERR_POS && ln > lim[t]) {
+            const u32 s_lo = lq + 4 > lim[t] ? lq + 4 : lim[t];
+            const u8* sp = src_base + R[t].src_off + s_lo;
+            u8* dp = cd + n_chars[t];
+            const u32 n = ln - s_lo, n16 = n & ~15u;
+            for (u32 c0 = lane * 16; c0 < n16; c0 += 64 * 16) *(u32x4_u*)(dp + c0) = *(const u32x4_u*)(sp + c0);
+            if (lane < 16 && n16 + lane < n) dp[n16 + lane] = sp[n16 + lane];
         }
     }
 }
@@ -1945,8 +1997,8 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
         }
     } else if (a.n_tiles) {
         if constexpr (KIND == KIND_STRINGS)
-            hipLaunchKernelGGL(k_str_mark, dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix, a.n_regions,
-                               a.tile_entry, (const u32x4*)a.str_cp, page_dyn, a.tile_region);
+            hipLaunchKernelGGL(k_str_mark, dim3((a.n_tiles + STR_MG - 1) / STR_MG), dim3(CH_THREADS), 0, st, src, a.regions,
+                               a.tile_prefix, a.n_regions, a.n_tiles, a.tile_entry, (const u32x4*)a.str_cp, page_dyn, a.tile_region);
         else
             hipLaunchKernelGGL((k_chain<KIND, true>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix,
                                a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn, a.tile_region);
