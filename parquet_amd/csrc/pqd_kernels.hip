@@ -1257,10 +1257,11 @@ __global__ __launch_bounds__(256) void k_levels_expand8(const u8* __restrict__ s
     u32 n_mine = 0;
     if (o0 < t_hi) n_mine = t_hi - o0 < 16 ? t_hi - o0 : 16;
     u8* dst = R.out + o0;
-    if (n_mine == 16 && (((u64)dst) & 15) == 0) {
+    if (n_mine == 16) {
+        // one 16-byte store at whatever alignment the page's first level has inside the chunk's array
         u32x4 v;
         v.x = (u32)acc_lo; v.y = (u32)(acc_lo >> 32); v.z = (u32)acc_hi; v.w = (u32)(acc_hi >> 32);
-        *(u32x4*)dst = v;
+        *(u32x4_u*)dst = v;
     } else {
         for (u32 k = 0; k < n_mine; k++) dst[k] = (u8)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8)));
     }
@@ -1417,10 +1418,10 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
     if (o0 < t_hi) n_mine = t_hi - o0 < 16 ? t_hi - o0 : 16;
     if (ESZ == 1) {
         u8* dst = R.out + o0;
-        if (n_mine == 16 && (((u64)dst) & 15) == 0) {
+        if (n_mine == 16) {
             u32x4 v;
             v.x = (u32)acc_lo; v.y = (u32)(acc_lo >> 32); v.z = (u32)acc_hi; v.w = (u32)(acc_hi >> 32);
-            *(u32x4*)dst = v;
+            *(u32x4_u*)dst = v;
         } else {
             for (u32 k = 0; k < n_mine; k++) dst[k] = (u8)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8)));
         }
