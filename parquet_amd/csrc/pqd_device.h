@@ -12,6 +12,7 @@ typedef uint64_t u64;
 
 constexpr u32 ERR_POS = 0xFFFFFFFFu;
 constexpr u32 UNKNOWN_POS = 0xFFFFFFFEu;  // group exit not tabulated
+constexpr u32 NO_SLOT = 0xFFFFFFFFu;      // an entry without a row in the exit table
 
 // device status codes (mapped to pqd_status by the host)
 constexpr int ST_CORRUPT = 1, ST_NONCANONICAL = 2, ST_UNSUPPORTED = 3;
@@ -71,7 +72,7 @@ struct Region {
 };
 
 struct ExitRec { u32 tgt; u32 cnt; u64 vals; };
-struct TileEntry { u32 pos; u32 cnt; u64 vals; u32 n; u32 pad; };  // n: elements that start in the tile (tile entries only)
+struct TileEntry { u32 pos; u32 cnt; u64 vals; u32 n; u32 slot; };  // tile entries only: n = elements that start in the tile, slot = the entry's row of the exit table
 struct RegionTotal { u32 cnt; u32 err; u64 vals; };
 struct RunRec { u32 out_off; u32 info; };
 
@@ -106,6 +107,11 @@ struct RowTile { u32 rows, vals; u64 row_base, val_base; };
 // ---- launchers -----------------------------------------------------------------------------
 hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32* blk_prefix, u32 n_segs, u32 n_blocks,
                        u32 max_grid);
+// strings: which positions of a chain tile are plausible string starts (see entry_slot in pqd_kernels.hip)
+struct StrIndex {
+    const unsigned short* map;   // n_tiles * 256 words: plausibility bits of 8 positions | plausible positions before them << 8
+    const unsigned short* cand;  // n_tiles * 64: tile offsets of the first 64 plausible positions, 0xFFFF = none
+};
 struct ChainArgs {
     const Region* regions;
     const u32* tile_prefix;   // n_regions + 1
@@ -122,6 +128,7 @@ struct ChainArgs {
     ExitRec* sexit;           // n_supers * E
     TileEntry* super_entry;   // n_supers  (reset to 0xFF before every run)
     const u32* tile_region;   // n_tiles: the region of every tile (optional; null: the kernels search tile_prefix)
+    StrIndex str_index;       // strings only (written by pass 1)
 };
 hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs& a, RunRec* run_tbl, u32* otile_first_run,
                         const PageDyn* page_dyn, int* status, int phase);

@@ -576,28 +576,57 @@ static __device__ __forceinline__ u32 str_len_at(const u32* s_tile, u32 rel) {
     return __builtin_amdgcn_alignbit(s_tile[d + 1], s_tile[d], (rel & 3) * 8);
 }
 
-// Pass 1 handles STR_TG tiles per wave.  Nearly every candidate start is not a string start and its chain
-// leaves the tile within a step or two (a random length overshoots the page), so a tile walked on its own
-// keeps two or three of its 64 lanes busy for ~85 steps.  Instead every tile's 64 candidates take STR_P1
-// steps (without leaving the tile's first 256-byte block, so no checkpoint is due yet), the chains still
-// inside their tile are packed into a queue, and the lanes walk the queue's chains to the end.
+// The row of a tile's exit table that belongs to tile offset off, from the map entry of off's 8 positions
+// (plausibility bits | plausible positions in front of them << 8); NO_SLOT when off is not among the first 64.
+static __device__ __forceinline__ u32 str_row(u32 word, u32 off) {  // word = the map entry of off's 8 positions
+    const u32 m = word & 0xFF, b = off & 7;
+    if (!((m >> b) & 1)) return NO_SLOT;
+    const u32 slot = (word >> 8) + __popc(m & ((1u << b) - 1));
+    return slot < CH_E_STRINGS ? slot : NO_SLOT;
+}
+
+// Pass 1, STR_TG tiles per wave.
+//   candidates  the positions of a tile whose four bytes are a length that fits in the page.  Every true string
+//               start is one; in text hardly anything else is.  The tile's exit table rows are its first 64
+//               candidates in position order, whatever their distance from the tile start: long strings enter a
+//               tile anywhere.  The plausibility bits of all positions and their running count go to str_map,
+//               which turns a position into its row (entry_slot), the positions of the rows to str_cand.
+//   one step    every row's candidate takes one step.  It leaves the tile (done), lands on another row's
+//               candidate (a link: from there on the two chains are one), or lands further on in the tile:
+//               only those few chains are walked to the end, packed into a queue so that the walks of all
+//               tiles share the lanes of the wave.
+//   links       pointer jumping over the 64 rows of every tile folds exits, string counts and checkpoints (the
+//               first position of the chain inside each 256-byte block, for pass 2) along the links.
+// Text tiles have at most one or two chains to walk (the true chain beyond its 64th candidate); tiles of
+// strings longer than ~30 bytes have none.
 constexpr u32 STR_TG = 4;
-constexpr u32 STR_P1 = 3;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ u32 min_u16x2(u32 a, u32 b) {
+    const u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(u32, r);
+}
 __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                           const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
                                                           ExitRec* __restrict__ exit_tbl, u32x4* __restrict__ str_cp,
-                                                          const u32* __restrict__ tile_region) {
-    static_assert(CH_E_STRINGS == CH_THREADS, "one lane per tabulated entry");
-    static_assert(STR_TG <= 8 && CH_T <= 2048 && STR_P1 < 16, "queue entry: 3 bits tile, 6 entry, 11 offset, count above");
+                                                          const u32* __restrict__ tile_region, unsigned short* __restrict__ str_map,
+                                                          unsigned short* __restrict__ str_cand) {
+    static_assert(CH_E_STRINGS == CH_THREADS, "one lane per row of a tile's exit table");
+    static_assert(STR_TG <= 8, "queue entry: 3 bits tile, offset above");
+    static_assert(STR_CP == 8, "a checkpoint row is 8 x u16");
+    constexpr u32 NO_LINK = 0xFF;
     __shared__ __attribute__((aligned(16))) u32 s_tile[STR_TG * STR_LDS_WORDS];
-    // checkpoints: the first position of the lane's chain inside each 256-byte block of the tile (tile
-    // offset; 0xFFFF = none).  Pass 2 splits its walk of the true chain at them.
-    __shared__ __attribute__((aligned(16))) u32 s_cp[CH_THREADS * STR_CP];
+    // first the plausibility words of the tiles (row lookup of the one-step landings), later the checkpoint
+    // rows of the walked chains (32-bit slots for the LDS atomic)
+    __shared__ __attribute__((aligned(16))) u64 s_mapcp[STR_TG * (CH_T / 32) > CH_THREADS * STR_CP / 2 ? STR_TG * (CH_T / 32) : CH_THREADS * STR_CP / 2];
+    static_assert(sizeof(s_mapcp) >= STR_TG * (CH_T / 8) * 2 && sizeof(s_mapcp) >= CH_THREADS * STR_CP * 4, "map words, then checkpoint rows");
     __shared__ u32 s_queue[STR_TG * CH_THREADS];
     __shared__ u32 s_tb[STR_TG], s_len[STR_TG];
     __shared__ u64 s_src[STR_TG];
+    __shared__ unsigned short s_cand[STR_TG][CH_E_STRINGS];
     const u32 lane = threadIdx.x, t0 = blockIdx.x * STR_TG;
     const u32 nt = n_tiles - t0 < STR_TG ? n_tiles - t0 : STR_TG;
+#pragma unroll
+    for (u32 t = 0; t < STR_TG; t++) s_cand[t][lane] = 0xFFFF;
     if (lane < nt) {
         const u32 ri = tile_region ? tile_region[t0 + lane] : find_owner(tile_prefix, n_regions, t0 + lane);
         const Region R = regions[ri];
@@ -632,73 +661,158 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
     }
     __syncthreads();
     const u64 lt = (1ull << lane) - 1;
-    const u32x4 none = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    // the first steps of all tiles side by side: eight independent chains per lane hide the LDS latency
-    u32 q[STR_TG], cnt[STR_TG], tbs[STR_TG], lens[STR_TG], lims[STR_TG];
+    u32 tbs[STR_TG], lens[STR_TG], lims[STR_TG];
 #pragma unroll
     for (u32 t = 0; t < STR_TG; t++) {
         tbs[t] = t < nt ? s_tb[t] : 0;
         lens[t] = t < nt ? s_len[t] : 0;
         lims[t] = tbs[t] + CH_T < lens[t] ? tbs[t] + CH_T : lens[t];
-        q[t] = t < nt ? tbs[t] + lane : ERR_POS;
-        cnt[t] = 0;
     }
-#pragma unroll
-    for (u32 k = 0; k < STR_P1; k++) {
-#pragma unroll
-        for (u32 t = 0; t < STR_TG; t++) {
-            const u32 lim1 = tbs[t] + STR_CP_BYTES < lims[t] ? tbs[t] + STR_CP_BYTES : lims[t];
-            const bool go = q[t] < lim1;
-            u32 nxt;
-            str_step_win(str_len_at(s_tile + t * STR_LDS_WORDS, go ? q[t] - tbs[t] : 0), go ? q[t] : 0, go ? lens[t] : 4, nxt);
-            q[t] = go ? nxt : q[t];
-            cnt[t] += go;
-        }
-    }
-    u32 qn = 0;
+    // ---- candidates, 512 positions (8 per lane) at a time until the tile has its 64 rows; a position p is one
+    // when len < max(L - 3 - p, 0), which is what str_step_win accepts (and is false for p >= L)
+    unsigned short* const s_map = (unsigned short*)s_mapcp;
 #pragma unroll
     for (u32 t = 0; t < STR_TG; t++) {
         if (t >= nt) break;
-        const bool alive = q[t] < lims[t];
-        const u64 bal = __ballot(alive);
-        if (alive) s_queue[qn + (u32)__popcll(bal & lt)] = t | (lane << 3) | ((q[t] - tbs[t]) << 9) | (cnt[t] << 20);
-        else {
-            ExitRec x;
-            x.tgt = q[t]; x.cnt = cnt[t]; x.vals = 0;
-            exit_tbl[(u64)(t0 + t) * CH_E_STRINGS + lane] = x;
-            str_cp[(u64)(t0 + t) * CH_THREADS + lane] = none;
+        u32 found = 0;
+        for (u32 c = 0; c < CH_T / 512; c++) {
+            u32 m = 0, pre = 255;
+            if (found < CH_E_STRINGS) {  // uniform
+                const u32 o = c * 512 + lane * 8;
+                const u32* tl = s_tile + t * STR_LDS_WORDS + o / 4;
+                const u32 x[3] = {tl[0], tl[1], tl[2]};
+                const int room = (int)(lens[t] - 3 - tbs[t] - o);  // L - 3 - p for my first position
+#pragma unroll
+                for (u32 k = 0; k < 8; k++) {
+                    const u32 len = (k & 3) ? __builtin_amdgcn_alignbit(x[k / 4 + 1], x[k / 4], (k & 3) * 8) : x[k / 4];
+                    const int r = room - (int)k;
+                    m |= (u32)(len < (u32)(r > 0 ? r : 0)) << k;
+                }
+                const u32 mine = __popc(m);
+                u32 incl = mine;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const u32 y = __shfl_up(incl, d);
+                    if (lane >= (u32)d) incl += y;
+                }
+                u32 slot = found + incl - mine;
+                pre = slot < 255 ? slot : 255;
+                found += __shfl(incl, 63);
+                u32 mm = m;
+                while (mm && slot < CH_E_STRINGS) {
+                    const u32 k = __ffs(mm) - 1;
+                    mm &= mm - 1;
+                    s_cand[t][slot++] = (unsigned short)(o + k);
+                }
+            }
+            const unsigned short word = (unsigned short)(m | (pre << 8));
+            str_map[(u64)(t0 + t) * (CH_T / 8) + c * 64 + lane] = word;
+            s_map[t * (CH_T / 8) + c * 64 + lane] = word;
+        }
+    }
+    __syncthreads();
+    // ---- one step per row; lane = row.  Per row and tile, in registers: where the chain leaves the tile,
+    // strings passed | link << 16, checkpoints (8 x u16)
+    u32 tg[STR_TG], cl[STR_TG], myq[STR_TG];
+    u32x4 rw[STR_TG];
+    u32 qn = 0;
+#pragma unroll
+    for (u32 t = 0; t < STR_TG; t++) {
+        tg[t] = ERR_POS; cl[t] = NO_LINK << 16; myq[t] = 0xFFFFFFFFu;
+        rw[t] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (t >= nt) continue;
+        const u32 c = s_cand[t][lane];
+        str_cand[(u64)(t0 + t) * CH_E_STRINGS + lane] = (unsigned short)c;
+        const bool have = c != 0xFFFF;
+        u32 nxt = ERR_POS;
+        if (have) str_step_win(str_len_at(s_tile + t * STR_LDS_WORDS, c), tbs[t] + c, lens[t], nxt);
+        const bool inside = nxt < lims[t];  // ERR_POS is not
+        const u32 rel = inside ? nxt - tbs[t] : 0;
+        const u32 row = str_row(s_map[t * (CH_T / 8) + (rel >> 3)], rel);
+        const bool linked = inside && row != NO_SLOT;
+        const bool walk = inside && !linked;
+        tg[t] = nxt;
+        cl[t] = (have ? 1u : 0u) | ((linked ? row : NO_LINK) << 16);
+        // the landing is the first position of my chain in its block
+        if (inside) {
+            const u32 k = rel / STR_CP_BYTES;
+            const u32 v = (k & 1) ? (0xFFFFu | (rel << 16)) : (0xFFFF0000u | rel);
+            if ((k >> 1) == 0) rw[t].x = v;
+            if ((k >> 1) == 1) rw[t].y = v;
+            if ((k >> 1) == 2) rw[t].z = v;
+            if ((k >> 1) == 3) rw[t].w = v;
+        }
+        const u64 bal = __ballot(walk);
+        if (walk) {
+            myq[t] = qn + (u32)__popcll(bal & lt);
+            s_queue[myq[t]] = t | (rel << 3);
         }
         qn += (u32)__popcll(bal);
     }
     __syncthreads();
+    // ---- the chains that neither left their tile nor met another row: walked to the end, 64 at a time, and
+    // handed back to the lanes of their rows
+    u32* const s_cp = (u32*)s_mapcp;
+    const u32x4 none = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     for (u32 base = 0; base < qn; base += CH_THREADS) {
         const bool have = base + lane < qn;
         const u32 e = have ? s_queue[base + lane] : 0;
-        const u32 t = e & 7, cand = (e >> 3) & 63;
+        const u32 t = e & 7;
         const u32 tb = s_tb[t], L = s_len[t];
         const u32 lim = tb + CH_T < L ? tb + CH_T : L;
         const u32* tl = s_tile + t * STR_LDS_WORDS;
         u32* cp = s_cp + lane * STR_CP;
         *(u32x4*)cp = none;
         *(u32x4*)(cp + 4) = none;
-        u32 qq = have ? tb + ((e >> 9) & 2047) : ERR_POS, c = e >> 20;
-        while (qq < lim) {  // ERR_POS ends the loop too
-            const u32 rel = qq - tb;
+        // the walk in tile offsets: a length is accepted when len < max(L - 3 - position, 0)
+        const u32 rlim = lim - tb;
+        const int room0 = (int)(L - 3 - tb);
+        u32 rel = have ? e >> 3 : ERR_POS, c = 1;
+        while (rel < rlim) {  // ERR_POS ends the loop too
             atomicMin(cp + rel / STR_CP_BYTES, rel);  // positions only grow: the first one of every block stays
-            u32 nxt;
-            str_step_win(str_len_at(tl, rel), qq, L, nxt);
+            const u32 len = str_len_at(tl, rel);
+            const int room = room0 - (int)rel;
+            rel = len < (u32)(room > 0 ? room : 0) ? rel + 4 + len : ERR_POS;
             c++;
-            qq = nxt;
         }
-        if (have) {
-            ExitRec x;
-            x.tgt = qq; x.cnt = c; x.vals = 0;
-            exit_tbl[(u64)(t0 + t) * CH_E_STRINGS + cand] = x;
-            // own row: no barrier needed.  Slot 0 is not a checkpoint (the walk of block 0 starts at the entry).
-            const u32x4 lo = *(const u32x4*)cp, hi = *(const u32x4*)(cp + 4);
-            str_cp[(u64)(t0 + t) * CH_THREADS + cand] =
-                u32x4{0xFFFFu | (lo.y << 16), (lo.z & 0xFFFFu) | (lo.w << 16), (hi.x & 0xFFFFu) | (hi.y << 16), (hi.z & 0xFFFFu) | (hi.w << 16)};
+        const u32 qq = rel == ERR_POS ? ERR_POS : tb + rel;
+        const u32x4 lo = *(const u32x4*)cp, hi = *(const u32x4*)(cp + 4);  // own row: no barrier needed
+        const u32x4 wr = u32x4{(lo.x & 0xFFFFu) | (lo.y << 16), (lo.z & 0xFFFFu) | (lo.w << 16),
+                               (hi.x & 0xFFFFu) | (hi.y << 16), (hi.z & 0xFFFFu) | (hi.w << 16)};
+#pragma unroll
+        for (u32 k = 0; k < STR_TG; k++) {
+            const bool mine = myq[k] != 0xFFFFFFFFu && myq[k] - base < CH_THREADS;  // walked in this batch
+            const u32 from = mine ? myq[k] - base : lane;
+            const u32 g_t = __shfl(qq, from), g_c = __shfl(c, from);
+            const u32 g_x = __shfl(wr.x, from), g_y = __shfl(wr.y, from), g_z = __shfl(wr.z, from), g_w = __shfl(wr.w, from);
+            if (mine) { tg[k] = g_t; cl[k] = g_c | (NO_LINK << 16); rw[k] = u32x4{g_x, g_y, g_z, g_w}; }
         }
+    }
+    // ---- links: a row's link points to a later row, so 6 rounds of pointer jumping reach the end of every list
+    for (u32 round = 0; round < 6; round++) {
+        bool any = false;
+#pragma unroll
+        for (u32 t = 0; t < STR_TG; t++) any = any || (cl[t] >> 16) != NO_LINK;
+        if (!__any(any)) break;
+#pragma unroll
+        for (u32 t = 0; t < STR_TG; t++) {
+            const bool linked = (cl[t] >> 16) != NO_LINK;
+            const u32 j = linked ? cl[t] >> 16 : lane;
+            const u32 tj = __shfl(tg[t], j), cj = __shfl(cl[t], j);
+            const u32 xj = __shfl(rw[t].x, j), yj = __shfl(rw[t].y, j), zj = __shfl(rw[t].z, j), wj = __shfl(rw[t].w, j);
+            if (linked) {
+                tg[t] = tj;
+                cl[t] = ((cl[t] & 0xFFFF) + (cj & 0xFFFF)) | (cj & 0xFFFF0000u);
+                rw[t] = u32x4{min_u16x2(rw[t].x, xj), min_u16x2(rw[t].y, yj), min_u16x2(rw[t].z, zj), min_u16x2(rw[t].w, wj)};
+            }
+        }
+    }
+#pragma unroll
+    for (u32 t = 0; t < STR_TG; t++) {
+        if (t >= nt) break;
+        ExitRec x;
+        x.tgt = tg[t]; x.cnt = cl[t] & 0xFFFF; x.vals = 0;
+        exit_tbl[(u64)(t0 + t) * CH_E_STRINGS + lane] = x;
+        str_cp[(u64)(t0 + t) * CH_THREADS + lane] = rw[t];
     }
 }
 
@@ -718,7 +832,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
     const u32 lane = threadIdx.x, t0 = blockIdx.x * STR_MG;
     // loads that do not depend on each other are issued together: entries and region indices, then the regions,
     // the entries' checkpoint rows and the pages' offsets
-    u32 epos[STR_MG], ecnt[STR_MG], ri[STR_MG];
+    u32 epos[STR_MG], ecnt[STR_MG], eslot[STR_MG], ri[STR_MG];
     bool on[STR_MG];
 #pragma unroll
     for (u32 t = 0; t < STR_MG; t++) {
@@ -726,7 +840,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
         const u32 tile = in ? t0 + t : t0;
         const TileEntry ent = tile_entry[tile];
         ri[t] = tile_region ? tile_region[tile] : find_owner(tile_prefix, n_regions, tile);
-        epos[t] = ent.pos; ecnt[t] = ent.cnt;
+        epos[t] = ent.pos; ecnt[t] = ent.cnt; eslot[t] = ent.slot;
         on[t] = in && ent.pos != ERR_POS;  // ERR_POS: no string starts in this tile
     }
     bool any = false;
@@ -735,13 +849,13 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
     if (!any) return;
     // walker lanes: lane l < 8 * STR_MG serves block l % 8 of tile l / 8
     const u32 wt = lane / STR_CP, wj = lane % STR_CP;
-    u32 w_epos = ERR_POS, w_tile = t0;
+    u32 w_epos = ERR_POS, w_tile = t0, w_slot = NO_SLOT;
 #pragma unroll
     for (u32 t = 0; t < STR_MG; t++)
-        if (wt == t && on[t]) { w_epos = epos[t]; w_tile = t0 + t; }
-    const u32 w_e = w_epos & (CH_T - 1);  // tiles start at multiples of CH_T of the region
+        if (wt == t && on[t]) { w_epos = epos[t]; w_tile = t0 + t; w_slot = eslot[t]; }
+    const u32 w_b0 = (w_epos & (CH_T - 1)) / STR_CP_BYTES;  // the entry's block; tiles start at multiples of CH_T of the region
     unsigned short cp = 0xFFFF;
-    if (w_epos != ERR_POS && w_e < CH_E_STRINGS) cp = ((const unsigned short*)(str_cp + (u64)w_tile * CH_THREADS + w_e))[wj];
+    if (w_epos != ERR_POS && w_slot != NO_SLOT) cp = ((const unsigned short*)(str_cp + (u64)w_tile * CH_THREADS + w_slot))[wj];
     Region R[STR_MG];
     PageDyn pd[STR_MG];
     u32 tb[STR_MG], lim[STR_MG];
@@ -761,8 +875,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
     }
     __syncthreads();
     // The true chain of a tile is walked by up to 8 lanes at once: pass 1 left, for the chain of every tabulated
-    // entry, its first position inside each 256-byte block of the tile; walker j takes block j.
-    // An entry beyond the tabulated window (a long string ends here) is walked by walker 0 alone.
+    // entry, its first position inside each 256-byte block of the tile after the entry's; walker j takes block j.
+    // An entry that pass 1 did not tabulate is walked by walker 0 alone.
     if (w_epos != ERR_POS) {
         u32 w_tb = 0, w_lim = 0, w_len = 0;
 #pragma unroll
@@ -771,10 +885,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
         const u32* tl = s_buf[wt];
         u32* bits = s_bits[wt];
         u32 q = ERR_POS, end = w_lim;
-        if (w_e >= CH_E_STRINGS) { if (wj == 0) q = w_epos; }
+        if (w_slot == NO_SLOT) { if (wj == 0) q = w_epos; }
         else {
-            if (wj == 0) q = w_epos;
-            else if (cp != 0xFFFF) q = w_tb + cp;
+            if (wj == w_b0) q = w_epos;
+            else if (wj > w_b0 && cp != 0xFFFF) q = w_tb + cp;
             const u32 b = w_tb + (wj + 1) * STR_CP_BYTES;
             end = b < w_lim ? b : w_lim;
         }
@@ -878,18 +992,43 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
 //   k_chain_resolve   one thread per region hops from group to group and records the group entries
 //   k_chain_tiles     one thread per group hops through its tiles and records the tile entries
 
-// One hop: the chain is at region position p (p < L); returns where it leaves p's tile.
+// Which row of an exit table belongs to an entry `off` bytes into the table's first tile (absolute tile index
+// `tile`).  Levels and snappy elements: the tables hold the first E byte positions.  Strings: the tables hold
+// the first E PLAUSIBLE string starts of the tile (positions whose four bytes are a length that fits in the
+// page), so that an entry anywhere in the tile is tabulated, not just one in its first bytes: strings longer
+// than a few dozen bytes enter a tile anywhere.  StrIndex::map has one 16-bit word per 8 positions: the
+// plausibility bits and, above them, the number of plausible positions in front of the word.
 template <int KIND>
+static __device__ __forceinline__ u32 entry_slot(const StrIndex& sx, u32 tile, u64 off) {
+    constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
+    if (KIND != KIND_STRINGS) return off < E ? (u32)off : NO_SLOT;
+    if (off >= CH_T) return NO_SLOT;
+    return str_row(sx.map[(u64)tile * (CH_T / 8) + ((u32)off >> 3)], (u32)off);
+}
+// Region position of entry row i of the table whose first tile is `tile` and starts at region position base.
+template <int KIND>
+static __device__ __forceinline__ u32 slot_pos(const StrIndex& sx, u32 tile, u32 base, u32 i) {
+    if (KIND != KIND_STRINGS) return base + i;
+    const u32 c = sx.cand[(u64)tile * CH_E_STRINGS + i];
+    return c == 0xFFFF ? ERR_POS : base + c;
+}
+
+// One hop: the chain is at region position p (p < L); returns where it leaves p's tile.  With WALK false
+// an entry that is not tabulated returns UNKNOWN_POS instead of being walked element by element.
+template <int KIND, bool WALK = true>
 static __device__ __forceinline__ u32 hop_tile(const Region& R, const GlobalBytes& B, const ExitRec* __restrict__ exit_tbl,
-                                               u32 p, u32& cnt, u64& vals) {
+                                               const StrIndex& sx, u32 p, u32& cnt, u64& vals, u32* slot_out = nullptr) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     const u32 L = R.len, t = p / CH_T, off = p % CH_T;
-    if (off < E) {
-        const ExitRec x = exit_tbl[(u64)(R.tile_base + t) * E + off];
+    const u32 slot = entry_slot<KIND>(sx, R.tile_base + t, off);
+    if (slot_out) *slot_out = slot;
+    if (slot != NO_SLOT) {
+        const ExitRec x = exit_tbl[(u64)(R.tile_base + t) * E + slot];
         cnt += x.cnt; vals += x.vals;
         return x.tgt;
     }
-    // entry beyond the tabulated window: walk this tile element by element
+    if (!WALK) return UNKNOWN_POS;
+    // entry not tabulated: walk this tile element by element
     const u32 tend = (t + 1) * CH_T < L ? (t + 1) * CH_T : L;
     u32 q = p;
     while (q < tend) {
@@ -906,46 +1045,46 @@ static __device__ __forceinline__ u32 hop_tile(const Region& R, const GlobalByte
 // the group exit table when the entry is tabulated there, tile by tile otherwise.
 template <int KIND>
 static __device__ __forceinline__ u32 hop_group(const Region& R, const GlobalBytes& B, const ExitRec* __restrict__ exit_tbl,
-                                                const ExitRec* __restrict__ gexit, u32 p, u32& cnt, u64& vals) {
+                                                const ExitRec* __restrict__ gexit, const StrIndex& sx, u32 p, u32& cnt, u64& vals) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     constexpr u32 G = chain_group_tiles(KIND);
     const u32 L = R.len, g = p / (G * CH_T), off = p - g * G * CH_T;
     ExitRec x;
     x.tgt = UNKNOWN_POS;
-    if (off < E) x = gexit[(u64)(R.group_base + g) * E + off];
+    const u32 slot = entry_slot<KIND>(sx, R.tile_base + g * G, off);
+    if (slot != NO_SLOT) x = gexit[(u64)(R.group_base + g) * E + slot];
     if (x.tgt != UNKNOWN_POS) {
         cnt += x.cnt; vals += x.vals;
         return x.tgt;
     }
     const u32 g_hi = (g + 1) * G * CH_T < L ? (g + 1) * G * CH_T : L;
-    while (p < g_hi) p = hop_tile<KIND>(R, B, exit_tbl, p, cnt, vals);
+    while (p < g_hi) p = hop_tile<KIND>(R, B, exit_tbl, sx, p, cnt, vals);
     return p;
 }
 
 template <int KIND>
 __global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                      const u32* __restrict__ group_prefix, u32 n_regions,
-                                                     const ExitRec* __restrict__ exit_tbl, ExitRec* __restrict__ gexit) {
+                                                     const ExitRec* __restrict__ exit_tbl, ExitRec* __restrict__ gexit,
+                                                     const StrIndex sx) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     constexpr u32 G = chain_group_tiles(KIND);
     const u32 group = blockIdx.x / (E / 64);
-    const u32 i = (blockIdx.x % (E / 64)) * 64 + threadIdx.x;  // entry offset into the group's first tile
+    const u32 i = (blockIdx.x % (E / 64)) * 64 + threadIdx.x;  // entry row of the group's first tile
     const u32 ri = find_owner(group_prefix, n_regions, group);
     const Region R = regions[ri];
     const u32 L = R.len;
     const u32 g_lo = (group - group_prefix[ri]) * G * CH_T;
     const u32 g_hi = g_lo + G * CH_T < L ? g_lo + G * CH_T : L;
     const GlobalBytes B{src_base + R.src_off};
-    u32 p = g_lo + i, cnt = 0;
+    u32 p = slot_pos<KIND>(sx, R.tile_base + (group - group_prefix[ri]) * G, g_lo, i), cnt = 0;
     u64 vals = 0;
-    if (p >= g_hi) return;
-    // Only one of the E candidate entries is the true one; a candidate whose chain lands beyond the
-    // tabulated window of some tile is given up (UNKNOWN_POS) rather than walked byte by byte: if it was
+    if (KIND != KIND_STRINGS && p >= g_hi) return;
+    // Only one of the E candidate entries is the true one; a candidate whose chain lands on an entry that
+    // some tile has not tabulated is given up (UNKNOWN_POS) rather than walked byte by byte: if it was
     // the true entry after all, k_chain_resolve hops that group tile by tile itself.
-    while (p < g_hi) {
-        if (p % CH_T >= E) { p = UNKNOWN_POS; break; }
-        p = hop_tile<KIND>(R, B, exit_tbl, p, cnt, vals);
-    }
+    if (p >= g_hi) p = UNKNOWN_POS;  // strings: a row without a candidate is never looked up
+    while (p < g_hi) p = hop_tile<KIND, false>(R, B, exit_tbl, sx, p, cnt, vals);
     ExitRec x;
     x.tgt = p; x.cnt = cnt; x.vals = vals;
     gexit[(u64)group * E + i] = x;
@@ -959,9 +1098,11 @@ __global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_
 template <int KIND>
 __global__ __launch_bounds__(64) void k_chain_supers(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                      const u32* __restrict__ super_prefix, u32 n_regions,
-                                                     const ExitRec* __restrict__ gexit, ExitRec* __restrict__ sexit) {
+                                                     const ExitRec* __restrict__ gexit, ExitRec* __restrict__ sexit,
+                                                     const StrIndex sx) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
-    constexpr u32 GB = chain_group_tiles(KIND) * CH_T;  // bytes per group
+    constexpr u32 G = chain_group_tiles(KIND);
+    constexpr u32 GB = G * CH_T;  // bytes per group
     const u32 sup = blockIdx.x / (E / 64);
     const u32 i = (blockIdx.x % (E / 64)) * 64 + threadIdx.x;
     const u32 ri = find_owner(super_prefix, n_regions, sup);
@@ -970,14 +1111,16 @@ __global__ __launch_bounds__(64) void k_chain_supers(const u8* __restrict__ src_
     const u64 s_lo64 = (u64)(sup - super_prefix[ri]) * CH_SUPER * GB;
     const u32 s_lo = (u32)s_lo64;
     const u32 s_hi = s_lo64 + (u64)CH_SUPER * GB < L ? (u32)(s_lo64 + (u64)CH_SUPER * GB) : L;
-    u32 p = s_lo + i, cnt = 0;
+    u32 p = slot_pos<KIND>(sx, R.tile_base + (sup - super_prefix[ri]) * CH_SUPER * G, s_lo, i), cnt = 0;
     u64 vals = 0;
-    if (p >= s_hi) return;
+    if (KIND != KIND_STRINGS && p >= s_hi) return;
+    if (p >= s_hi) p = UNKNOWN_POS;
     while (p < s_hi) {
         const u32 g = p / GB, off = p - g * GB;
         ExitRec x;
         x.tgt = UNKNOWN_POS;
-        if (off < E) x = gexit[(u64)(R.group_base + g) * E + off];
+        const u32 slot = entry_slot<KIND>(sx, R.tile_base + g * G, off);
+        if (slot != NO_SLOT) x = gexit[(u64)(R.group_base + g) * E + slot];
         if (x.tgt == UNKNOWN_POS) { p = UNKNOWN_POS; break; }  // not tabulated: the true chain is walked later
         cnt += x.cnt; vals += x.vals;
         p = x.tgt;
@@ -993,7 +1136,7 @@ __global__ void k_chain_resolve(const u8* __restrict__ src_base, const Region* _
                                 const u32* __restrict__ super_prefix, const ExitRec* __restrict__ sexit,
                                 TileEntry* __restrict__ super_entry,
                                 TileEntry* __restrict__ group_entry, RegionTotal* __restrict__ totals,
-                                int* __restrict__ status) {
+                                int* __restrict__ status, const StrIndex sx) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     constexpr u32 G = chain_group_tiles(KIND);
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1009,26 +1152,27 @@ __global__ void k_chain_resolve(const u8* __restrict__ src_base, const Region* _
             const u32 sg = (u32)(p / SB);
             const u64 off = p - sg * SB;
             TileEntry se;
-            se.pos = p; se.cnt = cnt; se.vals = vals; se.n = 0; se.pad = 0;
+            se.pos = p; se.cnt = cnt; se.vals = vals; se.n = 0; se.slot = 0;
             super_entry[super_prefix[r] + sg] = se;
             ExitRec x;
             x.tgt = UNKNOWN_POS;
-            if (off < E) x = sexit[(u64)(super_prefix[r] + sg) * E + off];
+            const u32 slot = entry_slot<KIND>(sx, R.tile_base + sg * CH_SUPER * G, off);
+            if (slot != NO_SLOT) x = sexit[(u64)(super_prefix[r] + sg) * E + slot];
             if (x.tgt != UNKNOWN_POS) {
                 cnt += x.cnt; vals += x.vals;
                 p = x.tgt;
             } else {
                 const u64 s_hi64 = (sg + 1) * SB;
                 const u32 s_hi = s_hi64 < L ? (u32)s_hi64 : L;
-                while (p < s_hi) p = hop_group<KIND>(R, B, exit_tbl, gexit, p, cnt, vals);
+                while (p < s_hi) p = hop_group<KIND>(R, B, exit_tbl, gexit, sx, p, cnt, vals);
             }
         }
     } else {
         while (p < L) {
             TileEntry ge;
-            ge.pos = p; ge.cnt = cnt; ge.vals = vals; ge.n = 0; ge.pad = 0;
+            ge.pos = p; ge.cnt = cnt; ge.vals = vals; ge.n = 0; ge.slot = 0;
             group_entry[R.group_base + p / (G * CH_T)] = ge;
-            p = hop_group<KIND>(R, B, exit_tbl, gexit, p, cnt, vals);
+            p = hop_group<KIND>(R, B, exit_tbl, gexit, sx, p, cnt, vals);
         }
     }
     const bool err = p == ERR_POS;
@@ -1044,7 +1188,8 @@ template <int KIND>
 __global__ void k_chain_super_groups(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                      const u32* __restrict__ super_prefix, u32 n_regions, u32 n_supers,
                                      const ExitRec* __restrict__ exit_tbl, const ExitRec* __restrict__ gexit,
-                                     const TileEntry* __restrict__ super_entry, TileEntry* __restrict__ group_entry) {
+                                     const TileEntry* __restrict__ super_entry, TileEntry* __restrict__ group_entry,
+                                     const StrIndex sx) {
     constexpr u32 G = chain_group_tiles(KIND);
     const u32 sup = blockIdx.x * blockDim.x + threadIdx.x;
     if (sup >= n_supers) return;
@@ -1061,9 +1206,9 @@ __global__ void k_chain_super_groups(const u8* __restrict__ src_base, const Regi
     u64 vals = se.vals;
     while (p < s_hi) {
         TileEntry ge;
-        ge.pos = p; ge.cnt = cnt; ge.vals = vals; ge.n = 0; ge.pad = 0;
+        ge.pos = p; ge.cnt = cnt; ge.vals = vals; ge.n = 0; ge.slot = 0;
         group_entry[R.group_base + p / (G * CH_T)] = ge;
-        p = hop_group<KIND>(R, B, exit_tbl, gexit, p, cnt, vals);
+        p = hop_group<KIND>(R, B, exit_tbl, gexit, sx, p, cnt, vals);
     }
 }
 
@@ -1071,7 +1216,7 @@ template <int KIND>
 __global__ void k_chain_tiles(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                               const u32* __restrict__ group_prefix, u32 n_regions, u32 n_groups,
                               const ExitRec* __restrict__ exit_tbl, const TileEntry* __restrict__ group_entry,
-                              TileEntry* __restrict__ tile_entry) {
+                              TileEntry* __restrict__ tile_entry, const StrIndex sx) {
     constexpr u32 G = chain_group_tiles(KIND);
     const u32 group = blockIdx.x * blockDim.x + threadIdx.x;
     if (group >= n_groups) return;
@@ -1087,9 +1232,9 @@ __global__ void k_chain_tiles(const u8* __restrict__ src_base, const Region* __r
     u64 vals = ge.vals;
     while (p < g_hi) {
         TileEntry te;
-        te.pos = p; te.cnt = cnt; te.vals = vals; te.pad = 0;
+        te.pos = p; te.cnt = cnt; te.vals = vals;
         const u32 idx = R.tile_base + p / CH_T;
-        p = hop_tile<KIND>(R, B, exit_tbl, p, cnt, vals);
+        p = hop_tile<KIND>(R, B, exit_tbl, sx, p, cnt, vals, &te.slot);  // the entry's table row (NO_SLOT: not tabulated)
         te.n = cnt - te.cnt;
         tile_entry[idx] = te;
     }
@@ -1965,35 +2110,37 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
         if (a.n_tiles) {
             if constexpr (KIND == KIND_STRINGS)
                 hipLaunchKernelGGL(k_str_exits, dim3((a.n_tiles + STR_TG - 1) / STR_TG), dim3(CH_THREADS), 0, st, src, a.regions,
-                                   a.tile_prefix, a.n_regions, a.n_tiles, a.exit_tbl, (u32x4*)a.str_cp, a.tile_region);
+                                   a.tile_prefix, a.n_regions, a.n_tiles, a.exit_tbl, (u32x4*)a.str_cp, a.tile_region,
+                                   (unsigned short*)a.str_index.map, (unsigned short*)a.str_index.cand);
             else
                 hipLaunchKernelGGL((k_chain<KIND, false>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions,
                                    a.tile_prefix, a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn,
                                    a.tile_region);
             LAUNCH_CHECK();
             hipLaunchKernelGGL((k_chain_groups<KIND>), dim3(a.n_groups * (E / 64)), dim3(64), 0, st, src, a.regions,
-                               a.group_prefix, a.n_regions, a.exit_tbl, a.gexit);
+                               a.group_prefix, a.n_regions, a.exit_tbl, a.gexit, a.str_index);
             LAUNCH_CHECK();
         }
         const bool supers = a.n_supers > 0;
         if (supers) {
             hipLaunchKernelGGL((k_chain_supers<KIND>), dim3(a.n_supers * (E / 64)), dim3(64), 0, st, src, a.regions,
-                               a.super_prefix, a.n_regions, a.gexit, a.sexit);
+                               a.super_prefix, a.n_regions, a.gexit, a.sexit, a.str_index);
             LAUNCH_CHECK();
         }
         // the region hop also runs for empty regions: it writes their (zero) totals
         hipLaunchKernelGGL((k_chain_resolve<KIND>), dim3((a.n_regions + 63) / 64), dim3(64), 0, st, src, a.regions, a.n_regions,
                            a.exit_tbl, a.gexit, a.super_prefix, supers ? a.sexit : nullptr, a.super_entry, a.group_entry,
-                           a.totals, status);
+                           a.totals, status, a.str_index);
         LAUNCH_CHECK();
         if (supers) {
             hipLaunchKernelGGL((k_chain_super_groups<KIND>), dim3((a.n_supers + 63) / 64), dim3(64), 0, st, src, a.regions,
-                               a.super_prefix, a.n_regions, a.n_supers, a.exit_tbl, a.gexit, a.super_entry, a.group_entry);
+                               a.super_prefix, a.n_regions, a.n_supers, a.exit_tbl, a.gexit, a.super_entry, a.group_entry,
+                               a.str_index);
             LAUNCH_CHECK();
         }
         if (a.n_tiles) {
             hipLaunchKernelGGL((k_chain_tiles<KIND>), dim3((a.n_groups + 63) / 64), dim3(64), 0, st, src, a.regions,
-                               a.group_prefix, a.n_regions, a.n_groups, a.exit_tbl, a.group_entry, a.tile_entry);
+                               a.group_prefix, a.n_regions, a.n_groups, a.exit_tbl, a.group_entry, a.tile_entry, a.str_index);
             LAUNCH_CHECK();
         }
     } else if (a.n_tiles) {

@@ -278,6 +278,36 @@ def test_strings_fixed_strides_and_giants(ctx):
     assert bytes(g[(0, "s")]["chars"]) == b"".join(parts)
 
 
+def test_strings_of_mixed_lengths_text(ctx):
+    """Text strings from 0 to a few tiles long in one column: short ones give a tile more plausible starts than
+    its exit table has rows, long ones make the chain enter tiles far from their first bytes, and the mix
+    puts both next to each other (entries tabulated, linked, walked and, past the table, hopped serially)."""
+    rng = np.random.default_rng(18)
+    cols = [Column("s", N.BYTE_ARRAY, [1])]
+    for ranges in (((61, 100),), ((100, 400),), ((0, 3), (61, 100), (100, 400), (0, 3), (2000, 5000), (8, 32))):
+        w = ParquetWriter(cols, stats=False)
+        w.begin_row_group()
+        n_rows = 0
+        for page in range(3):
+            lens = np.concatenate([rng.integers(lo, hi + 1, int(rng.integers(50, 4000) if hi < 1000 else rng.integers(5, 40))) for lo, hi in ranges])
+            if len(ranges) > 1:
+                rng.shuffle(lens[: len(lens) // 2])  # first half mixed at random, second half in blocks of one kind
+            offs = np.zeros(len(lens) + 1, np.int32)
+            np.cumsum(lens, out=offs[1:])
+            chars = rng.integers(97, 123, int(offs[-1]), dtype=np.uint8)
+            defs = (rng.random(int(len(lens) * 1.1) + 1) > 0.09).astype(np.uint8)
+            while int(defs.sum()) < len(lens):
+                defs = np.concatenate([defs, np.ones(len(lens) - int(defs.sum()), np.uint8)])
+            nz = np.flatnonzero(defs)
+            defs = defs[: nz[len(lens) - 1] + 1]  # exactly len(lens) non-null slots
+            w.write_page(0, chars, defs=defs, offsets=offs)
+            n_rows += len(defs)
+        w.end_row_group(n_rows)
+        buf = w.finish()
+        w.close()
+        H.check_file(buf, ctx)
+
+
 def test_strings_that_look_like_length_prefixes(ctx):
     """Chars drawn from {0, 1, 2}: almost every byte of the page is a plausible length prefix, so the false
     candidate chains of the chain kernels are as long as they can get."""
