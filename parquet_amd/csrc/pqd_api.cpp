@@ -441,6 +441,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_scp = ap.take((size_t)pl->n_stiles_chain * CH_THREADS * 16);
     const size_t o_smap = ap.take((size_t)pl->n_stiles_chain * (CH_T / 8) * 2);
     const size_t o_scand = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * 2);
+    const size_t o_sncand = ap.take((size_t)pl->n_stiles_chain * 2), o_sgpre = ap.take((size_t)pl->n_stiles_chain * 2);
+    const size_t o_sspre = ap.take((size_t)pl->n_stiles_chain * 2);
     const u32 n_lgroups = pl->lgroup_prefix.back(), n_sgroups = pl->sgroup_prefix.back();
     const size_t o_lgexit = ap.take((size_t)n_lgroups * CH_E_LEVELS * sizeof(ExitRec));
     const size_t o_sgexit = ap.take((size_t)n_sgroups * CH_E_STRINGS * sizeof(ExitRec));
@@ -552,7 +554,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                            (u32*)(A + o_ssp), n_ssupers, (ExitRec*)(A + o_ssexit), (TileEntry*)(A + o_sse)};
     pl->lchain.tile_region = (u32*)(A + o_ltr);
     pl->schain.tile_region = (u32*)(A + o_str);
-    pl->schain.str_index = StrIndex{(const unsigned short*)(A + o_smap), (const unsigned short*)(A + o_scand)};
+    pl->schain.str_index = StrIndex{(const unsigned short*)(A + o_smap), (const unsigned short*)(A + o_scand),
+                                    (const unsigned short*)(A + o_sncand), (unsigned short*)(A + o_sgpre), (unsigned short*)(A + o_sspre)};
 
     int rc;
     if ((rc = upload(ctx, pl->d_chunks, pl->chunks))) return rc;

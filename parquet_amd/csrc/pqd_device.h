@@ -111,6 +111,9 @@ hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32
 struct StrIndex {
     const unsigned short* map;   // n_tiles * 256 words: plausibility bits of 8 positions | plausible positions before them << 8
     const unsigned short* cand;  // n_tiles * 64: tile offsets of the first 64 plausible positions, 0xFFFF = none
+    const unsigned short* ncand; // n_tiles: plausible positions of the tile (counted until its 64 rows were full)
+    unsigned short* gpre;        // n_tiles: plausible positions in the earlier tiles of the tile's group (k_chain_groups)
+    unsigned short* spre;        // n_tiles: ... of the tile's super-group (k_chain_supers)
 };
 struct ChainArgs {
     const Region* regions;

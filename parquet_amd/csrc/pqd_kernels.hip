@@ -609,7 +609,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
                                                           const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
                                                           ExitRec* __restrict__ exit_tbl, u32x4* __restrict__ str_cp,
                                                           const u32* __restrict__ tile_region, unsigned short* __restrict__ str_map,
-                                                          unsigned short* __restrict__ str_cand) {
+                                                          unsigned short* __restrict__ str_cand, unsigned short* __restrict__ str_ncand) {
     static_assert(CH_E_STRINGS == CH_THREADS, "one lane per row of a tile's exit table");
     static_assert(STR_TG <= 8, "queue entry: 3 bits tile, offset above");
     static_assert(STR_CP == 8, "a checkpoint row is 8 x u16");
@@ -708,6 +708,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
             str_map[(u64)(t0 + t) * (CH_T / 8) + c * 64 + lane] = word;
             s_map[t * (CH_T / 8) + c * 64 + lane] = word;
         }
+        if (lane == 0) str_ncand[t0 + t] = (unsigned short)found;  // counted until the table was full
     }
     __syncthreads();
     // ---- one step per row; lane = row.  Per row and tile, in registers: where the chain leaves the tile,
@@ -998,19 +999,46 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
 // page), so that an entry anywhere in the tile is tabulated, not just one in its first bytes: strings longer
 // than a few dozen bytes enter a tile anywhere.  StrIndex::map has one 16-bit word per 8 positions: the
 // plausibility bits and, above them, the number of plausible positions in front of the word.
-template <int KIND>
-static __device__ __forceinline__ u32 entry_slot(const StrIndex& sx, u32 tile, u64 off) {
+// The tables of a group (LEVEL 1) and of a super-group (LEVEL 2) hold the first E plausible starts of ALL their
+// tiles, so that a chain of strings longer than a tile, which enters most groups beyond their first tile, is
+// still tabulated: a start's row there is its row in its own tile plus the plausible starts of the group's
+// (super-group's) earlier tiles (StrIndex::gpre / spre, written by k_chain_groups / k_chain_supers).
+// `first` = absolute index of the table's first tile, off = offset of the entry from that tile's start.
+template <int KIND, int LEVEL>
+static __device__ __forceinline__ u32 entry_slot(const StrIndex& sx, u32 first, u64 off) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     if (KIND != KIND_STRINGS) return off < E ? (u32)off : NO_SLOT;
-    if (off >= CH_T) return NO_SLOT;
-    return str_row(sx.map[(u64)tile * (CH_T / 8) + ((u32)off >> 3)], (u32)off);
+    const u32 tile = first + (u32)(off / CH_T), o = (u32)(off % CH_T);
+    const u32 row = str_row(sx.map[(u64)tile * (CH_T / 8) + (o >> 3)], o);
+    if (LEVEL == 0 || row == NO_SLOT) return row;
+    const u32 r = row + (LEVEL == 1 ? sx.gpre[tile] : sx.spre[tile]);
+    return r < E ? r : NO_SLOT;
 }
-// Region position of entry row i of the table whose first tile is `tile` and starts at region position base.
-template <int KIND>
-static __device__ __forceinline__ u32 slot_pos(const StrIndex& sx, u32 tile, u32 base, u32 i) {
+// Region position of row i of the table whose first tile is `first` (absolute index) and starts at region
+// position base; the table spans n_scope tiles.  ERR_POS: the table has fewer rows.
+template <int KIND, int LEVEL>
+static __device__ __forceinline__ u32 slot_pos(const StrIndex& sx, u32 first, u32 base, u32 i, u32 n_scope) {
     if (KIND != KIND_STRINGS) return base + i;
-    const u32 c = sx.cand[(u64)tile * CH_E_STRINGS + i];
-    return c == 0xFFFF ? ERR_POS : base + c;
+    constexpr u32 G = chain_group_tiles(KIND_STRINGS);
+    u32 t_lo = 0, t_hi = n_scope, acc = 0;
+    if (LEVEL == 2) {  // find the group first: its total is the prefix of its last tile plus that tile's count
+        t_hi = 0;
+        for (u32 g0 = 0; g0 < n_scope; g0 += G) {
+            const u32 last = first + (g0 + G < n_scope ? g0 + G : n_scope) - 1;
+            const u32 tot = (u32)sx.gpre[last] + sx.ncand[last];
+            if (i < acc + tot) { t_lo = g0; t_hi = g0 + G < n_scope ? g0 + G : n_scope; break; }
+            acc += tot;
+        }
+    }
+    for (u32 t = t_lo; t < t_hi; t++) {
+        const u32 n = sx.ncand[first + t];
+        if (i < acc + n) {
+            const u32 c = sx.cand[(u64)(first + t) * CH_E_STRINGS + (i - acc)];  // i - acc < n and i < 64
+            return c == 0xFFFF ? ERR_POS : base + t * CH_T + c;
+        }
+        acc += n;
+    }
+    return ERR_POS;
 }
 
 // One hop: the chain is at region position p (p < L); returns where it leaves p's tile.  With WALK false
@@ -1020,7 +1048,7 @@ static __device__ __forceinline__ u32 hop_tile(const Region& R, const GlobalByte
                                                const StrIndex& sx, u32 p, u32& cnt, u64& vals, u32* slot_out = nullptr) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     const u32 L = R.len, t = p / CH_T, off = p % CH_T;
-    const u32 slot = entry_slot<KIND>(sx, R.tile_base + t, off);
+    const u32 slot = entry_slot<KIND, 0>(sx, R.tile_base + t, off);
     if (slot_out) *slot_out = slot;
     if (slot != NO_SLOT) {
         const ExitRec x = exit_tbl[(u64)(R.tile_base + t) * E + slot];
@@ -1051,7 +1079,7 @@ static __device__ __forceinline__ u32 hop_group(const Region& R, const GlobalByt
     const u32 L = R.len, g = p / (G * CH_T), off = p - g * G * CH_T;
     ExitRec x;
     x.tgt = UNKNOWN_POS;
-    const u32 slot = entry_slot<KIND>(sx, R.tile_base + g * G, off);
+    const u32 slot = entry_slot<KIND, 1>(sx, R.tile_base + g * G, off);
     if (slot != NO_SLOT) x = gexit[(u64)(R.group_base + g) * E + slot];
     if (x.tgt != UNKNOWN_POS) {
         cnt += x.cnt; vals += x.vals;
@@ -1077,7 +1105,14 @@ __global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_
     const u32 g_lo = (group - group_prefix[ri]) * G * CH_T;
     const u32 g_hi = g_lo + G * CH_T < L ? g_lo + G * CH_T : L;
     const GlobalBytes B{src_base + R.src_off};
-    u32 p = slot_pos<KIND>(sx, R.tile_base + (group - group_prefix[ri]) * G, g_lo, i), cnt = 0;
+    const u32 t_first = (group - group_prefix[ri]) * G, n_rt = (L + CH_T - 1) / CH_T;
+    const u32 n_scope = n_rt - t_first < G ? n_rt - t_first : G;
+    if (KIND == KIND_STRINGS && i < n_scope) {  // plausible starts in front of every tile of the group
+        u32 acc = 0;
+        for (u32 t = 0; t < i; t++) acc += sx.ncand[R.tile_base + t_first + t];
+        sx.gpre[R.tile_base + t_first + i] = (unsigned short)(acc < 0xFFFF ? acc : 0xFFFF);
+    }
+    u32 p = slot_pos<KIND, 1>(sx, R.tile_base + t_first, g_lo, i, n_scope), cnt = 0;
     u64 vals = 0;
     if (KIND != KIND_STRINGS && p >= g_hi) return;
     // Only one of the E candidate entries is the true one; a candidate whose chain lands on an entry that
@@ -1111,7 +1146,29 @@ __global__ __launch_bounds__(64) void k_chain_supers(const u8* __restrict__ src_
     const u64 s_lo64 = (u64)(sup - super_prefix[ri]) * CH_SUPER * GB;
     const u32 s_lo = (u32)s_lo64;
     const u32 s_hi = s_lo64 + (u64)CH_SUPER * GB < L ? (u32)(s_lo64 + (u64)CH_SUPER * GB) : L;
-    u32 p = slot_pos<KIND>(sx, R.tile_base + (sup - super_prefix[ri]) * CH_SUPER * G, s_lo, i), cnt = 0;
+    const u32 t_first = (sup - super_prefix[ri]) * CH_SUPER * G, n_rt = (L + CH_T - 1) / CH_T;
+    const u32 n_scope = n_rt - t_first < CH_SUPER * G ? n_rt - t_first : CH_SUPER * G;
+    if (KIND == KIND_STRINGS) {  // plausible starts in front of every tile of the super-group: groups before + inside the group
+        u32 tot = 0;
+        if (i * G < n_scope) {
+            const u32 last = R.tile_base + t_first + ((i + 1) * G < n_scope ? (i + 1) * G : n_scope) - 1;
+            tot = (u32)sx.gpre[last] + sx.ncand[last];
+        }
+        u32 incl = tot;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 y = __shfl_up(incl, d);
+            if (i >= (u32)d) incl += y;
+        }
+        const u32 excl = incl - tot;  // lane g: plausible starts in groups 0..g-1
+        for (u32 k = i; k < CH_SUPER * G; k += 64) {
+            const u32 before = __shfl(excl, k / G);
+            if (k < n_scope) {
+                const u32 v = before + sx.gpre[R.tile_base + t_first + k];
+                sx.spre[R.tile_base + t_first + k] = (unsigned short)(v < 0xFFFF ? v : 0xFFFF);
+            }
+        }
+    }
+    u32 p = slot_pos<KIND, 2>(sx, R.tile_base + t_first, s_lo, i, n_scope), cnt = 0;
     u64 vals = 0;
     if (KIND != KIND_STRINGS && p >= s_hi) return;
     if (p >= s_hi) p = UNKNOWN_POS;
@@ -1119,7 +1176,7 @@ __global__ __launch_bounds__(64) void k_chain_supers(const u8* __restrict__ src_
         const u32 g = p / GB, off = p - g * GB;
         ExitRec x;
         x.tgt = UNKNOWN_POS;
-        const u32 slot = entry_slot<KIND>(sx, R.tile_base + g * G, off);
+        const u32 slot = entry_slot<KIND, 1>(sx, R.tile_base + g * G, off);
         if (slot != NO_SLOT) x = gexit[(u64)(R.group_base + g) * E + slot];
         if (x.tgt == UNKNOWN_POS) { p = UNKNOWN_POS; break; }  // not tabulated: the true chain is walked later
         cnt += x.cnt; vals += x.vals;
@@ -1156,7 +1213,7 @@ __global__ void k_chain_resolve(const u8* __restrict__ src_base, const Region* _
             super_entry[super_prefix[r] + sg] = se;
             ExitRec x;
             x.tgt = UNKNOWN_POS;
-            const u32 slot = entry_slot<KIND>(sx, R.tile_base + sg * CH_SUPER * G, off);
+            const u32 slot = entry_slot<KIND, 2>(sx, R.tile_base + sg * CH_SUPER * G, off);
             if (slot != NO_SLOT) x = sexit[(u64)(super_prefix[r] + sg) * E + slot];
             if (x.tgt != UNKNOWN_POS) {
                 cnt += x.cnt; vals += x.vals;
@@ -2111,7 +2168,8 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
             if constexpr (KIND == KIND_STRINGS)
                 hipLaunchKernelGGL(k_str_exits, dim3((a.n_tiles + STR_TG - 1) / STR_TG), dim3(CH_THREADS), 0, st, src, a.regions,
                                    a.tile_prefix, a.n_regions, a.n_tiles, a.exit_tbl, (u32x4*)a.str_cp, a.tile_region,
-                                   (unsigned short*)a.str_index.map, (unsigned short*)a.str_index.cand);
+                                   (unsigned short*)a.str_index.map, (unsigned short*)a.str_index.cand,
+                                   (unsigned short*)a.str_index.ncand);
             else
                 hipLaunchKernelGGL((k_chain<KIND, false>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions,
                                    a.tile_prefix, a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn,

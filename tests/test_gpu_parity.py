@@ -308,6 +308,26 @@ def test_strings_of_mixed_lengths_text(ctx):
         H.check_file(buf, ctx)
 
 
+def test_strings_longer_than_tiles_across_groups_and_super_groups(ctx):
+    """Hundreds of strings of several KiB: nearly every 2 KiB tile is entered far from its start or not at all,
+    and the chain enters most groups of 16 tiles and super-groups of 256 beyond their first tile."""
+    rng = np.random.default_rng(19)
+    cols = [Column("s", N.BYTE_ARRAY, [0])]
+    for lo, hi, n in ((3000, 9000, 700), (2049, 2049, 1500), (40000, 70000, 40)):
+        w = ParquetWriter(cols, stats=False)
+        w.begin_row_group()
+        lens = rng.integers(lo, hi + 1, n)
+        offs = np.zeros(n + 1, np.int32)
+        np.cumsum(lens, out=offs[1:])
+        chars = rng.integers(97, 123, int(offs[-1]), dtype=np.uint8)
+        w.write_page(0, chars, offsets=offs)
+        w.end_row_group(n)
+        buf = w.finish()
+        w.close()
+        o, g = H.check_file(buf, ctx)
+        assert bytes(g[(0, "s")]["chars"]) == chars.tobytes()
+
+
 def test_strings_that_look_like_length_prefixes(ctx):
     """Chars drawn from {0, 1, 2}: almost every byte of the page is a plausible length prefix, so the false
     candidate chains of the chain kernels are as long as they can get."""
