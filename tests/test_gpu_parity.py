@@ -579,6 +579,28 @@ def _random_level_block(rng, width, min_values):
     return len(body).to_bytes(4, "little") + bytes(body), total
 
 
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fuzz_whole_files(ctx, seed):
+    """Random schemas (every physical type, required / optional / repeated paths), page and row-group sizes, null
+    rates, string lengths from empty to several tiles, text and binary alphabets, both codecs."""
+    rng = np.random.default_rng(4000 + seed)
+    phys = [N.INT32, N.INT64, N.FLOAT, N.DOUBLE, N.BOOLEAN, N.BYTE_ARRAY, N.BYTE_ARRAY]
+    shapes = [[0], [1], [1, 1], [2], [2, 1], [1, 2, 0], [2, 2, 1]]
+    cols = []
+    for ci in range(int(rng.integers(2, 7))):
+        t = shapes[int(rng.integers(0, len(shapes)))]
+        cols.append(Column(".".join("f%dl%d" % (ci, i) for i in range(len(t))), phys[int(rng.integers(0, len(phys)))], t))
+    n_rows = int(rng.integers(1, 6000))
+    group = int(rng.integers(1, n_rows + 1))
+    page = int(rng.integers(1, group + 1))
+    lo = int(rng.choice([0, 0, 1, 8, 50, 300]))
+    hi = lo + int(rng.choice([0, 3, 30, 200, 3000]))
+    alphabet = [(97, 123), (0, 256), (0, 3)][int(rng.integers(0, 3))]
+    buf = H.build_file(cols, n_rows, group, page, rng, p_null=float(rng.choice([0.0, 0.05, 0.5, 1.0])), str_len=(lo, hi),
+                       alphabet=alphabet, stats=bool(rng.integers(0, 2)), codec=int(rng.integers(0, 2)))
+    H.check_file(buf, ctx)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_fuzz_level_blocks_through_pages(ctx, seed):
     rng = np.random.default_rng(100 + seed)
