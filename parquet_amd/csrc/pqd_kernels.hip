@@ -1009,10 +1009,11 @@ static __device__ __forceinline__ u32 entry_slot(const StrIndex& sx, u32 first, 
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     if (KIND != KIND_STRINGS) return off < E ? (u32)off : NO_SLOT;
     const u32 tile = first + (u32)(off / CH_T), o = (u32)(off % CH_T);
-    const u32 row = str_row(sx.map[(u64)tile * (CH_T / 8) + (o >> 3)], o);
-    if (LEVEL == 0 || row == NO_SLOT) return row;
-    const u32 r = row + (LEVEL == 1 ? sx.gpre[tile] : sx.spre[tile]);
-    return r < E ? r : NO_SLOT;
+    const u32 word = sx.map[(u64)tile * (CH_T / 8) + (o >> 3)];
+    const u32 pre = LEVEL == 0 ? 0 : LEVEL == 1 ? sx.gpre[tile] : sx.spre[tile];  // both loads in flight together
+    const u32 row = str_row(word, o);
+    if (row == NO_SLOT) return row;
+    return row + pre < E ? row + pre : NO_SLOT;
 }
 // Region position of row i of the table whose first tile is `first` (absolute index) and starts at region
 // position base; the table spans n_scope tiles.  ERR_POS: the table has fewer rows.
@@ -1020,23 +1021,33 @@ template <int KIND, int LEVEL>
 static __device__ __forceinline__ u32 slot_pos(const StrIndex& sx, u32 first, u32 base, u32 i, u32 n_scope) {
     if (KIND != KIND_STRINGS) return base + i;
     constexpr u32 G = chain_group_tiles(KIND_STRINGS);
-    u32 t_lo = 0, t_hi = n_scope, acc = 0;
+    u32 t_lo = 0, acc = 0;
     if (LEVEL == 2) {  // find the group first: its total is the prefix of its last tile plus that tile's count
-        t_hi = 0;
-        for (u32 g0 = 0; g0 < n_scope; g0 += G) {
-            const u32 last = first + (g0 + G < n_scope ? g0 + G : n_scope) - 1;
-            const u32 tot = (u32)sx.gpre[last] + sx.ncand[last];
-            if (i < acc + tot) { t_lo = g0; t_hi = g0 + G < n_scope ? g0 + G : n_scope; break; }
-            acc += tot;
+        u32 tot[CH_SUPER];  // loaded up front: uniform addresses, no dependent round trips
+#pragma unroll
+        for (u32 g = 0; g < CH_SUPER; g++) {
+            const u32 last = first + ((g + 1) * G < n_scope ? (g + 1) * G : n_scope) - 1;
+            tot[g] = g * G < n_scope ? (u32)sx.gpre[last] + sx.ncand[last] : 0;
         }
+        u32 g_hit = CH_SUPER;
+#pragma unroll
+        for (u32 g = 0; g < CH_SUPER; g++) {
+            if (g_hit == CH_SUPER && i < acc + tot[g]) g_hit = g;
+            if (g_hit == CH_SUPER) acc += tot[g];
+        }
+        if (g_hit == CH_SUPER) return ERR_POS;
+        t_lo = g_hit * G;
     }
-    for (u32 t = t_lo; t < t_hi; t++) {
-        const u32 n = sx.ncand[first + t];
-        if (i < acc + n) {
-            const u32 c = sx.cand[(u64)(first + t) * CH_E_STRINGS + (i - acc)];  // i - acc < n and i < 64
-            return c == 0xFFFF ? ERR_POS : base + t * CH_T + c;
+    u32 n[G];
+#pragma unroll
+    for (u32 t = 0; t < G; t++) n[t] = t_lo + t < n_scope ? sx.ncand[first + t_lo + t] : 0;
+#pragma unroll
+    for (u32 t = 0; t < G; t++) {
+        if (i < acc + n[t]) {
+            const u32 c = sx.cand[(u64)(first + t_lo + t) * CH_E_STRINGS + (i - acc)];  // i - acc < n and i < 64
+            return c == 0xFFFF ? ERR_POS : base + (t_lo + t) * CH_T + c;
         }
-        acc += n;
+        acc += n[t];
     }
     return ERR_POS;
 }
@@ -1109,7 +1120,11 @@ __global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_
     const u32 n_scope = n_rt - t_first < G ? n_rt - t_first : G;
     if (KIND == KIND_STRINGS && i < n_scope) {  // plausible starts in front of every tile of the group
         u32 acc = 0;
-        for (u32 t = 0; t < i; t++) acc += sx.ncand[R.tile_base + t_first + t];
+#pragma unroll
+        for (u32 t = 0; t < G; t++) {
+            const u32 n = t < n_scope ? sx.ncand[R.tile_base + t_first + t] : 0;  // uniform addresses
+            if (t < i) acc += n;
+        }
         sx.gpre[R.tile_base + t_first + i] = (unsigned short)(acc < 0xFFFF ? acc : 0xFFFF);
     }
     u32 p = slot_pos<KIND, 1>(sx, R.tile_base + t_first, g_lo, i, n_scope), cnt = 0;
