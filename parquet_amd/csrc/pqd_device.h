@@ -72,6 +72,7 @@ struct Region {
 };
 
 struct ExitRec { u32 tgt; u32 cnt; u64 vals; };
+struct StrExit { u32 tgt; u32 cnt; };  // the tile-level rows of string chains (no value counts); same array
 struct TileEntry { u32 pos; u32 cnt; u64 vals; u32 n; u32 slot; };  // tile entries only: n = elements that start in the tile, slot = the entry's row of the exit table
 struct RegionTotal { u32 cnt; u32 err; u64 vals; };
 struct RunRec { u32 out_off; u32 info; };

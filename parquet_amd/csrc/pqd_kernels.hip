@@ -810,9 +810,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
 #pragma unroll
     for (u32 t = 0; t < STR_TG; t++) {
         if (t >= nt) break;
-        ExitRec x;
-        x.tgt = tg[t]; x.cnt = cl[t] & 0xFFFF; x.vals = 0;
-        exit_tbl[(u64)(t0 + t) * CH_E_STRINGS + lane] = x;
+        StrExit x;
+        x.tgt = tg[t]; x.cnt = cl[t] & 0xFFFF;
+        ((StrExit*)exit_tbl)[(u64)(t0 + t) * CH_E_STRINGS + lane] = x;
         str_cp[(u64)(t0 + t) * CH_THREADS + lane] = rw[t];
     }
 }
@@ -1062,6 +1062,11 @@ static __device__ __forceinline__ u32 hop_tile(const Region& R, const GlobalByte
     const u32 slot = entry_slot<KIND, 0>(sx, R.tile_base + t, off);
     if (slot_out) *slot_out = slot;
     if (slot != NO_SLOT) {
+        if (KIND == KIND_STRINGS) {  // string rows are {exit, strings passed}: 8 bytes
+            const StrExit x = ((const StrExit*)exit_tbl)[(u64)(R.tile_base + t) * E + slot];
+            cnt += x.cnt;
+            return x.tgt;
+        }
         const ExitRec x = exit_tbl[(u64)(R.tile_base + t) * E + slot];
         cnt += x.cnt; vals += x.vals;
         return x.tgt;
