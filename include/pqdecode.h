@@ -72,10 +72,10 @@ typedef enum {
     PQD_OUT_CHARS = 4,        /* concatenated string bytes */
     PQD_OUT_VALIDITY = 5,     /* bitmap, bit i (LSB first) = (defs[i] == max_def)   (fields.go:220-228 per level) */
     PQD_OUT_PAGE_NONNULL = 6, /* int64[n_pages] — the `sizes` of DoRead (fields.go:124, :311-312) */
-    PQD_OUT_ROW_LEVEL_OFF = 7,/* int64[n_rows+1] — first level of each row (write_repeated.go:62-80); only for
+    PQD_OUT_ROW_LEVEL_OFF = 7,/* int32[n_rows+1] — first level of each row (write_repeated.go:62-80); only for
                                  repeated columns (max_rep > 0): otherwise row r is level r and its value index is
                                  the number of set validity bits before r */
-    PQD_OUT_ROW_VALUE_OFF = 8 /* int64[n_rows+1] — first value of each row; repeated columns only */
+    PQD_OUT_ROW_VALUE_OFF = 8 /* int32[n_rows+1] — first value of each row; repeated columns only */
 } pqd_output;
 
 typedef struct {

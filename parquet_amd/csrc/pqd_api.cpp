@@ -291,6 +291,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
             stream += P.val_len;
             pl->bytes_in += pd.payload_len;
         }
+        if (levels > 0x7ffffff0ull) return fail(ctx, PQD_E_UNSUPPORTED, "column chunk with 2^31 levels or more");  // int32 row offsets, 32-bit level indices
         C.n_levels = levels;
         C.stream_len = stream;
         C.req_values = (u64)cd.num_values;
@@ -321,8 +322,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         }
         if (C.max_rep > 0) {
             want(PQD_OUT_REPS, C.n_levels);
-            want(PQD_OUT_ROW_LEVEL_OFF, (C.n_levels + 1) * 8);
-            want(PQD_OUT_ROW_VALUE_OFF, (C.n_levels + 1) * 8);
+            want(PQD_OUT_ROW_LEVEL_OFF, (C.n_levels + 1) * 4);
+            want(PQD_OUT_ROW_VALUE_OFF, (C.n_levels + 1) * 4);
         }
         if (C.width_bytes) want(PQD_OUT_VALUES, C.stream_len);
         else if (C.phys_type == PQD_BOOLEAN) want(PQD_OUT_VALUES, C.n_levels);
@@ -768,7 +769,7 @@ int64_t pqd_plan_fetch(pqd_plan* pl, size_t c, pqd_output which, void* dst, size
     case PQD_OUT_CHARS: n = (size_t)ci.chars_bytes; break;
     case PQD_OUT_VALIDITY: n = ((size_t)ci.n_levels + 7) / 8; break;
     case PQD_OUT_PAGE_NONNULL: n = (size_t)ci.n_pages * 8; break;
-    case PQD_OUT_ROW_LEVEL_OFF: case PQD_OUT_ROW_VALUE_OFF: n = ((size_t)ci.n_rows + 1) * 8; break;
+    case PQD_OUT_ROW_LEVEL_OFF: case PQD_OUT_ROW_VALUE_OFF: n = ((size_t)ci.n_rows + 1) * 4; break;
     }
     if (n > pl->outs[c].cap[which]) n = pl->outs[c].cap[which];
     if (n > cap) return fail(ctx, PQD_E_ARG, "destination too small");

@@ -2110,11 +2110,12 @@ __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunk
     __syncthreads();
     const RowTile T = tiles[rt];
     const u64 lvl0 = (u64)(rt - rtile_prefix[k]) * RT;
-    u64* rl = (u64*)C.row_level_off + T.row_base;
-    u64* rv = (u64*)C.row_value_off + T.row_base;
+    // int32: a chunk holds fewer than 2^31 levels (checked when the plan is made)
+    int32_t* rl = (int32_t*)C.row_level_off + T.row_base;
+    int32_t* rv = (int32_t*)C.row_value_off + T.row_base;
     for (u32 j = threadIdx.x; j < tot_r; j += 256) {
-        rl[j] = lvl0 + s_rl[j];
-        rv[j] = T.val_base + s_rv[j];
+        rl[j] = (int32_t)(lvl0 + s_rl[j]);
+        rv[j] = (int32_t)(T.val_base + s_rv[j]);
     }
 }
 
@@ -2159,8 +2160,8 @@ __global__ __launch_bounds__(1024) void k_rows_scan(const ChunkRec* __restrict__
     }
     if (tid == 0) {
         chunk_dyn[c].n_rows = tot_r;
-        ((u64*)C.row_level_off)[tot_r] = C.n_levels;
-        ((u64*)C.row_value_off)[tot_r] = tot_v;
+        ((int32_t*)C.row_level_off)[tot_r] = (int32_t)C.n_levels;
+        ((int32_t*)C.row_value_off)[tot_r] = (int32_t)tot_v;
     }
 }
 

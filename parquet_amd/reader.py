@@ -171,7 +171,7 @@ class Plan:
             N.OUT_DEFS: ci.n_levels, N.OUT_REPS: ci.n_levels, N.OUT_VALUES: ci.value_bytes,
             N.OUT_OFFSETS: (ci.n_values + 1) * 4, N.OUT_CHARS: ci.chars_bytes,
             N.OUT_VALIDITY: (ci.n_levels + 7) // 8, N.OUT_PAGE_NONNULL: ci.n_pages * 8,
-            N.OUT_ROW_LEVEL_OFF: (ci.n_rows + 1) * 8, N.OUT_ROW_VALUE_OFF: (ci.n_rows + 1) * 8,
+            N.OUT_ROW_LEVEL_OFF: (ci.n_rows + 1) * 4, N.OUT_ROW_VALUE_OFF: (ci.n_rows + 1) * 4,
         }
         if not self.device_ptr(chunk, which):
             return np.zeros(0, dtype)
@@ -190,8 +190,8 @@ class Plan:
             out["validity"] = self.fetch(chunk, N.OUT_VALIDITY)
         if cd.max_rep > 0:
             out["reps"] = self.fetch(chunk, N.OUT_REPS)
-            out["row_level_off"] = self.fetch(chunk, N.OUT_ROW_LEVEL_OFF, np.int64)
-            out["row_value_off"] = self.fetch(chunk, N.OUT_ROW_VALUE_OFF, np.int64)
+            out["row_level_off"] = self.fetch(chunk, N.OUT_ROW_LEVEL_OFF, np.int32)
+            out["row_value_off"] = self.fetch(chunk, N.OUT_ROW_VALUE_OFF, np.int32)
         elif cd.max_def > 0:
             # not repeated: row r is level r (write_optional.go:22-31); its first value is the number of
             # non-null levels before it
