@@ -39,7 +39,7 @@ constexpr u32 CH_T = CH_THREADS * CH_SUB;  // source bytes per tile (2048)
 constexpr u32 CH_WIN = CH_SUB / 4 + 2;    // dwords a lane holds: its sub-tile + 8 bytes of lookahead
 constexpr u32 CH_E_LEVELS = 256;  // tabulated entry positions per tile: covers the reference writer's longest
                                   // run (1 + 63 groups x 4 bytes); longer jumps take the serial hop
-constexpr u32 CH_E_STRINGS = 64;  // covers values up to 60 bytes; longer ones take the serial hop
+constexpr u32 CH_E_STRINGS = 64;  // rows per tile: its first 64 plausible string starts (see StrIndex)
 
 constexpr u32 CH_SERIAL = 64;     // level tiles with at most this many runs are marked by a serial walk
 constexpr u32 CH_G_LEVELS = 8;    // tiles per hop group (level blocks are ~60 tiles per 1M-value page)

@@ -524,17 +524,18 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
 // =====================================================================================
 // PLAIN BYTE_ARRAY chains.  A length prefix is cheap to parse and a wrong start dies fast (a random
 // length overshoots the page), so strings do not need the every-byte sweep of k_chain:
-//   k_str_exits   pass 1: follows the chain that starts at byte i of the tile (i < E = 64) through an LDS
-//                 copy of the tile until it leaves the tile; the exit table gets where it left and how
-//                 many strings it passed.  Same table, same hop kernels as the level chains.
-//   k_str_mark    pass 2: lane 0 walks the true chain from the tile's true entry and sets one bit per
+//   k_str_exits   pass 1: the rows of a tile's exit table are its first 64 plausible string starts (positions
+//                 whose four bytes are a length that fits in the page), wherever they lie in the tile; for
+//                 each, where its chain leaves the tile and how many strings it passes.  Same hop kernels
+//                 as the level chains, with the row of an entry looked up through StrIndex.
+//   k_str_mark    pass 2: up to 8 lanes walk the true chain from the tile's true entry and set one bit per
 //                 string start; the wave then writes offsets[] (rank = prefix popcount) and the chars:
 //                 every byte of the tile from the true entry on is a length byte or a char, chars are
 //                 dense in the output, so they are compacted through LDS and leave as aligned 16-byte
 //                 stores; the part of the tile's last string beyond the tile is copied by the whole wave.
 // =====================================================================================
 constexpr u32 STR_LDS_WORDS = CH_T / 4 + 4;
-constexpr u32 STR_CP = 8;                       // checkpoints per chain (slot 0 unused)
+constexpr u32 STR_CP = 8;                       // checkpoints per chain: one per 256-byte block of the tile
 constexpr u32 STR_CP_BYTES = CH_T / STR_CP;     // one every 256 bytes
 static_assert(STR_CP * 2 == 16, "a checkpoint row is one 16-byte store");
 
