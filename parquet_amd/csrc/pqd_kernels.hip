@@ -249,27 +249,35 @@ static __device__ __forceinline__ void elem_step(const Bytes& B, u32 p, u32 L, u
 
 // Bytes k..k+7 / k..k+3 of a lane's register image w[] (its sub-tile plus 8 bytes of lookahead); k is a
 // compile-time constant after unrolling, so these are plain register funnel shifts.
-static __device__ __forceinline__ u64 win64(const u32 (&w)[CH_WIN], int k) {
+template <u32 N>
+static __device__ __forceinline__ u64 win64(const u32 (&w)[N], int k) {
     const int d = k >> 2, sh = (k & 3) * 8;
     const u32 lo = sh ? (w[d] >> sh) | (w[d + 1] << (32 - sh)) : w[d];
     const u32 hi = sh ? (w[d + 1] >> sh) | (w[d + 2] << (32 - sh)) : w[d + 1];
     return lo | ((u64)hi << 32);
 }
-static __device__ __forceinline__ u32 win32(const u32 (&w)[CH_WIN], int k) {
+template <u32 N>
+static __device__ __forceinline__ u32 win32(const u32 (&w)[N], int k) {
     const int d = k >> 2, sh = (k & 3) * 8;
     return sh ? (w[d] >> sh) | (w[d + 1] << (32 - sh)) : w[d];
 }
 
-template <int KIND, bool MARK>
-__global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+template <int KIND, bool MARK, u32 NT>
+__global__ __launch_bounds__(NT) void k_chain(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                       const u32* __restrict__ tile_prefix, u32 n_regions,
                                                       ExitRec* __restrict__ exit_tbl, const TileEntry* __restrict__ tile_entry,
                                                       RunRec* __restrict__ run_tbl, u32* __restrict__ otile_first_run,
                                                       const PageDyn* __restrict__ page_dyn, const u32* __restrict__ tile_region) {
     static_assert(KIND != KIND_STRINGS, "strings have their own chain kernels");
+    // NT threads share the tile: a thread's sub-tile is SUB = CH_T / NT bytes.  Two waves per tile halve every
+    // thread's sweeps; the LDS memo (one entry per start) and with it the tiles resident per CU stay the same,
+    // so twice the waves hide the latency of the LDS round trips.
+    constexpr u32 SUB = CH_T / NT, WIN = SUB / 4 + 2, PITCH = NT + 1;
+    static_assert(SUB == 16 || SUB == 32, "window loads below");
+    auto memo_at = [](u32 rel) { return (rel % SUB) * PITCH + rel / SUB; };
     constexpr u32 E = CH_E_LEVELS;
     constexpr u32 OTK = KIND == KIND_SNAPPY ? SN_T : OT;  // output bytes per tile of the kernel that consumes the records
-    constexpr u32 MEMO = CH_SUB * 65;
+    constexpr u32 MEMO = SUB * PITCH;
     // memo per start: exit position, elements passed, and (levels) level values passed.  Levels keep
     // {exit, values} in one 8-byte entry so that a lookup is a single LDS read.
     __shared__ u64 m_tv[MEMO];
@@ -282,8 +290,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
     auto memo_put = [&](u32 mi, u32 tgt, u32 val) {
         m_tv[mi] = (u64)tgt | ((u64)val << 32);
     };
-    __shared__ u32 e_pos[MARK ? 64 : 1], e_cnt[MARK ? 64 : 1];
-    __shared__ u64 e_val[MARK ? 64 : 1];
+    __shared__ u32 e_pos[MARK ? NT : 1], e_cnt[MARK ? NT : 1];
+    __shared__ u64 e_val[MARK ? NT : 1];
 
     const u32 lane = threadIdx.x;
     const u32 tile = blockIdx.x;
@@ -302,17 +310,21 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
     }
 
     // my sub-tile and 8 bytes of lookahead, in registers; bytes at or past L read as 0
-    const u32 sub_lo = tb + lane * CH_SUB, sub_hi = sub_lo + CH_SUB;
-    u32 w[CH_WIN];
-    if (sub_lo + 4 * CH_WIN <= L) {
-        // whole window inside the region: three independent wide loads (any alignment)
-        const u32x4 a = *(const u32x4_u*)(rsrc + sub_lo), b = *(const u32x4_u*)(rsrc + sub_lo + 16);
-        const u64 c = *(const u64_u*)(rsrc + sub_lo + 32);
-        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-        w[8] = (u32)c; w[9] = (u32)(c >> 32);
+    const u32 sub_lo = tb + lane * SUB, sub_hi = sub_lo + SUB;
+    u32 w[WIN];
+    if (sub_lo + 4 * WIN <= L) {
+        // whole window inside the region: independent wide loads (any alignment)
+        const u32x4 a = *(const u32x4_u*)(rsrc + sub_lo);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+        if constexpr (SUB == 32) {
+            const u32x4 b = *(const u32x4_u*)(rsrc + sub_lo + 16);
+            w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        }
+        const u64 c = *(const u64_u*)(rsrc + sub_lo + SUB);
+        w[SUB / 4] = (u32)c; w[SUB / 4 + 1] = (u32)(c >> 32);
     } else {
 #pragma unroll
-        for (int d = 0; d < (int)CH_WIN; d++) {
+        for (int d = 0; d < (int)WIN; d++) {
             const u32 p = sub_lo + 4 * d;
             u32 v = 0;
             if (p < L) {
@@ -329,8 +341,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
         __shared__ u32 r_out[CH_SERIAL + 1], r_info[CH_SERIAL], r_n;
         u32* const tb32 = (u32*)m_tv;  // the memo table is not used on this path
 #pragma unroll
-        for (int d = 0; d < 8; d++) tb32[lane * 8 + d] = w[d];
-        if (lane == 63) { tb32[512] = w[8]; tb32[513] = w[9]; tb32[514] = 0; tb32[515] = 0; }
+        for (int d = 0; d < (int)(SUB / 4); d++) tb32[lane * (SUB / 4) + d] = w[d];
+        if (lane == NT - 1) { tb32[512] = w[SUB / 4]; tb32[513] = w[SUB / 4 + 1]; tb32[514] = 0; tb32[515] = 0; }
         __syncthreads();
         const u32 n_out = (u32)R.n_out;
         if (lane == 0) {
@@ -374,9 +386,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
 
     // ---- sweep 1: every start of my sub-tile learns where its chain leaves the sub-tile.  The marking
     // pass keeps each start's own step (next start, values, record) in registers for the replay below.
-    u32 st_nxt[MARK ? CH_SUB : 1], st_val[MARK ? CH_SUB : 1], st_info[MARK ? CH_SUB : 1];
+    u32 st_nxt[MARK ? SUB : 1], st_val[MARK ? SUB : 1], st_info[MARK ? SUB : 1];
 #pragma unroll
-    for (int k = CH_SUB - 1; k >= 0; k--) {
+    for (int k = (int)SUB - 1; k >= 0; k--) {
         const u32 p = sub_lo + k;
         const bool valid = p < L;
         u32 nxt, vals = 0;
@@ -404,9 +416,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
         if (MARK) st_nxt[k] = nxt;
         // a step that lands on a later start of this sub-tile takes over that start's memoised answer
         // (the lookup is unconditional: lanes without one read their own slot and drop the result)
-        const u32 mi = (u32)k * 65 + lane;
+        const u32 mi = (u32)k * PITCH + lane;
         const bool in = (nxt < sub_hi) & (nxt < L);
-        const u32 mj = in ? (nxt - sub_lo) * 65 + lane : mi;
+        const u32 mj = in ? (nxt - sub_lo) * PITCH + lane : mi;
         u32 t2, v2;
         memo_get(mj, t2, v2);
         const u32 c2 = m_cnt[mj];
@@ -423,16 +435,17 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
         // ---- sweep 2, level A: sub-tile exits -> exits of groups of 8 sub-tiles (256 bytes).  Inside every
         // group, sub-tiles from last to first (all 8 groups at once, 4 starts per lane): a start whose
         // chain lands on a later start of its group takes over that start's already final answer.
-        for (int j = 6; j >= 0; j--) {
+        constexpr u32 GS = 256 / SUB;  // sub-tiles per group
+        for (int j = (int)GS - 2; j >= 0; j--) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const u32 g = 2 * i + (lane >> 5), k = lane & 31;
-                const u32 rel = (g * 8 + (u32)j) * CH_SUB + k;
-                const u32 mi = k * 65 + g * 8 + (u32)j;
+            for (int i = 0; i < (int)(8 * SUB / NT); i++) {
+                const u32 item = (u32)i * NT + lane, g = item / SUB, k = item % SUB;
+                const u32 rel = (g * GS + (u32)j) * SUB + k;
+                const u32 mi = k * PITCH + g * GS + (u32)j;
                 u32 t, v;
                 memo_get(mi, t, v);
-                if (tb + rel < L && t < tb + (g + 1) * 8 * CH_SUB && t < L) {
-                    const u32 mj = memo_idx(t - tb);
+                if (tb + rel < L && t < tb + (g + 1) * GS * SUB && t < L) {
+                    const u32 mj = memo_at(t - tb);
                     u32 t2, v2;
                     memo_get(mj, t2, v2);
                     memo_put(mi, t2, sat_add32(v, v2));
@@ -443,12 +456,12 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
         }
         // ---- level B: only the first E starts of the tile need their tile exit; each hops from group to
         // group (at most 7 hops) through the level-A answers and goes to the exit table.
-        constexpr int PER = E / 64;
+        constexpr int PER = E / NT;
         u32 ht[PER], hc[PER], hv[PER];
 #pragma unroll
         for (int i = 0; i < PER; i++) {
-            const u32 rel = (u32)i * 64 + lane;  // E <= 256: all inside group 0
-            const u32 mi = memo_idx(rel);
+            const u32 rel = (u32)i * NT + lane;  // E <= 256: all inside group 0
+            const u32 mi = memo_at(rel);
             memo_get(mi, ht[i], hv[i]);
             hc[i] = m_cnt[mi];
         }
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
 #pragma unroll
             for (int i = 0; i < PER; i++) {
                 if (ht[i] < te && ht[i] < L) {
-                    const u32 mj = memo_idx(ht[i] - tb);
+                    const u32 mj = memo_at(ht[i] - tb);
                     u32 t2, v2;
                     memo_get(mj, t2, v2);
                     hc[i] += m_cnt[mj];
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
             x.tgt = ht[i];
             x.cnt = hc[i];
             x.vals = hv[i];
-            exit_tbl[(u64)tile * E + (u32)i * 64 + lane] = x;
+            exit_tbl[(u64)tile * E + (u32)i * NT + lane] = x;
         }
         return;
     }
@@ -484,7 +497,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
         u32 q = ent.pos, c = ent.cnt;
         u64 v = ent.vals;
         while (q < te && q < L) {
-            const u32 rel = q - tb, sidx = rel / CH_SUB, mi = memo_idx(rel);
+            const u32 rel = q - tb, sidx = rel / SUB, mi = memo_at(rel);
             e_pos[sidx] = q; e_cnt[sidx] = c; e_val[sidx] = v;
             u32 t2, v2;
             memo_get(mi, t2, v2);
@@ -504,7 +517,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain(const u8* __restrict__ src
     RunRec* const runs = run_tbl + R.run_base;
     u32* const ofr = otile_first_run + R.otile_base;
 #pragma unroll
-    for (int k = 0; k < (int)CH_SUB; k++) {
+    for (int k = 0; k < (int)SUB; k++) {
         if (q == sub_lo + k && q < L) {
             const u32 vals = st_val[k];
             RunRec rr;
@@ -2180,6 +2193,10 @@ hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32
     return hipSuccess;
 }
 
+// Threads per tile of k_chain (levels, snappy elements).  Pass 1 is all sweeps and takes two waves per tile
+// (levels: 60 -> 42 us on 4100 tiles); the marking pass has one lane chain over the sub-tiles, which twice as
+// many sub-tiles make longer (73 -> 82 us), so it keeps one wave.
+constexpr u32 CHAIN_NT = 128, CHAIN_NT_MARK = 64;
 template <int KIND>
 static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs& a, RunRec* run_tbl, u32* otile_first_run,
                                  const PageDyn* page_dyn, int* status, int phase) {
@@ -2193,7 +2210,7 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
                                    (unsigned short*)a.str_index.map, (unsigned short*)a.str_index.cand,
                                    (unsigned short*)a.str_index.ncand);
             else
-                hipLaunchKernelGGL((k_chain<KIND, false>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions,
+                hipLaunchKernelGGL((k_chain<KIND, false, CHAIN_NT>), dim3(a.n_tiles), dim3(CHAIN_NT), 0, st, src, a.regions,
                                    a.tile_prefix, a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn,
                                    a.tile_region);
             LAUNCH_CHECK();
@@ -2228,7 +2245,7 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
             hipLaunchKernelGGL(k_str_mark, dim3((a.n_tiles + STR_MG - 1) / STR_MG), dim3(CH_THREADS), 0, st, src, a.regions,
                                a.tile_prefix, a.n_regions, a.n_tiles, a.tile_entry, (const u32x4*)a.str_cp, page_dyn, a.tile_region);
         else
-            hipLaunchKernelGGL((k_chain<KIND, true>), dim3(a.n_tiles), dim3(CH_THREADS), 0, st, src, a.regions, a.tile_prefix,
+            hipLaunchKernelGGL((k_chain<KIND, true, CHAIN_NT_MARK>), dim3(a.n_tiles), dim3(CHAIN_NT_MARK), 0, st, src, a.regions, a.tile_prefix,
                                a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn, a.tile_region);
         LAUNCH_CHECK();
     }
