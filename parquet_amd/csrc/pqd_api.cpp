@@ -438,7 +438,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_rtp = ap.take(pl->rtile_prefix.size() * 4);
     // scratch
     const size_t o_lexit = ap.take((size_t)pl->n_ltiles * CH_E_LEVELS * sizeof(ExitRec));
-    const size_t o_sexit = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * sizeof(ExitRec));
+    const size_t o_sexit = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * sizeof(StrExit));
     const size_t o_scp = ap.take((size_t)pl->n_stiles_chain * CH_THREADS * 16);
     const size_t o_smap = ap.take((size_t)pl->n_stiles_chain * (CH_T / 8) * 2);
     const size_t o_scand = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * 2);
