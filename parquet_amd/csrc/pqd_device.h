@@ -41,7 +41,7 @@ constexpr u32 CH_E_LEVELS = 256;  // tabulated entry positions per tile: covers 
                                   // run (1 + 63 groups x 4 bytes); longer jumps take the serial hop
 constexpr u32 CH_E_STRINGS = 64;  // rows per tile: its first 64 plausible string starts (see StrIndex)
 
-constexpr u32 CH_SERIAL = 64;     // level tiles with at most this many runs are marked by a serial walk
+constexpr u32 CH_SERIAL = 32;     // level tiles with at most this many runs are marked by a serial walk
 constexpr u32 CH_G_LEVELS = 8;    // tiles per hop group (level blocks are ~60 tiles per 1M-value page)
 constexpr u32 CH_G_STRINGS = 16;  // tiles per hop group (string pages are thousands of tiles: they get a super level)
 constexpr u32 CH_G_SNAPPY = 64;   // tiles per hop group of a snappy block
