@@ -38,6 +38,14 @@ def build_all(force=False):
     synth = os.path.join(LIB, "libpqsynth.so")
     if force or _stale(synth, SYNTH_DEPS):
         _run([os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", synth] + SYNTH_SOURCES)
+    # the C++ mirror of the generated reader (include/pqreader.hpp) in a small program that the GPU tests run
+    root = os.path.dirname(HERE)
+    demo_src = os.path.join(root, "tests", "cpp", "read_rows.cpp")
+    demo = os.path.join(LIB, "pq_read_rows")
+    demo_deps = [demo_src, os.path.join(root, "include", "pqreader.hpp"), os.path.join(root, "include", "pqdecode.h"), decode]
+    if os.path.exists(demo_src) and (force or not os.path.exists(demo) or any(os.path.getmtime(d) > os.path.getmtime(demo) for d in demo_deps)):
+        _run([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(root, "include"), demo_src,
+              "-o", demo, "-L", LIB, "-lpqdecode", "-Wl,-rpath,$ORIGIN"])
     return decode, synth
 
 

@@ -56,6 +56,27 @@ int main(int argc, char** argv) {
     assert out[0] == "500" and int(out[1]) == 8 * 2 * 3  # 8 columns, 2 row groups of 250 rows, 3 pages of <= 100 rows each
 
 
+def test_cpp_reader_mirror_builds_and_fails_loudly_without_a_device(tmp_path):
+    """include/pqreader.hpp (NewParquetReader / Next / Scan / Rows / Error over the C ABI) compiles warning-free,
+    rejects a file that is not Parquet, and reports the missing device instead of falling back to anything."""
+    import subprocess
+    lib = os.path.join(ROOT, "parquet_amd", "lib")
+    exe = str(tmp_path / "read_rows")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "read_rows.cpp"), "-o", exe, "-L", lib, "-lpqdecode", "-Wl,-rpath," + lib],
+                   check=True)
+    bad = tmp_path / "bad.parquet"
+    bad.write_bytes(b"PAR1 not a parquet file PAR1")
+    p = subprocess.run([exe, str(bad)], capture_output=True, text=True)
+    assert p.returncode == 1 and p.stdout.startswith("error")
+    import torch
+    if not torch.cuda.is_available():
+        good = tmp_path / "good.parquet"
+        good.write_bytes(bytes(_flat_file(np.random.default_rng(12), n=200, page=50, group=100)[2]))
+        p = subprocess.run([exe, str(good)], capture_output=True, text=True)
+        assert p.returncode == 1 and "device" in p.stdout
+
+
 def test_no_device_means_loud_failure():
     import torch
     if torch.cuda.is_available():
