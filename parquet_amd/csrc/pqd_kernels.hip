@@ -1821,7 +1821,9 @@ __global__ void k_str_check(const Region* __restrict__ regions, u32 n_regions, c
 // across a tile boundary; a stream that does is reported as unsupported rather than decoded wrongly.
 // d < offset (a copy reaching before the start of the output) is ErrCorrupt.
 // =====================================================================================
-__global__ __launch_bounds__(256) void k_snappy_tiles(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+constexpr u32 SN_THREADS = 256;  // 4 waves per 64 KiB tile (8 are 11 % faster on text and 12 % slower on long runs,
+                                  // where the extra waves only wait; 6 fit one tile per CU and lose everywhere)
+__global__ __launch_bounds__(SN_THREADS) void k_snappy_tiles(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                       const u32* __restrict__ otile_region, const RunRec* __restrict__ run_tbl,
                                                       const u32* __restrict__ otile_first_run,
                                                       const RegionTotal* __restrict__ totals, int* __restrict__ status) {
@@ -1845,7 +1847,7 @@ __global__ __launch_bounds__(256) void k_snappy_tiles(const u8* __restrict__ src
     u32 last = T.cnt;
     if (next_same && nf != ERR_POS && nf + 1 < last) last = nf + 1;
 
-    for (u32 i = tid; i < SN_T / 32; i += 256) s_fin[i] = 0;
+    for (u32 i = tid; i < SN_T / 32; i += SN_THREADS) s_fin[i] = 0;
     if (tid == 0) s_next = first;
     __syncthreads();
     // sets the bits of tile bytes [a, b), all lanes of a wave together
@@ -1861,7 +1863,7 @@ __global__ __launch_bounds__(256) void k_snappy_tiles(const u8* __restrict__ src
     };
     // ---- 1. literals.  Short ones (the common case) are done lane-parallel, one 16-byte load each, so
     // that 64 global loads are in flight per wave; long ones are copied by the whole wave in turn.
-    for (u32 base = first + wv * 64; base < last; base += 256) {
+    for (u32 base = first + wv * 64; base < last; base += SN_THREADS) {
         const u32 e = base + lane;
         u32 lo = 0, hi = 0, sp = 0;
         bool lit = false;
@@ -1880,12 +1882,31 @@ __global__ __launch_bounds__(256) void k_snappy_tiles(const u8* __restrict__ src
             u32x4 v[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) v[c] = 16u * c < n ? load_u128_guarded(rsrc, sp + 16 * c, R.len) : u32x4{0, 0, 0, 0};
+            // LDS takes stores at any alignment: whole 8-byte pieces, and for the rest two overlapping stores
+            // of the largest power of two that fits (first bytes, last bytes) instead of a byte loop
             u8* d = s_o + (lo - B);
+            const u64 v_lo = v[0].x | ((u64)v[0].y << 32), v_hi = v[0].z | ((u64)v[0].w << 32);
+            if (n >= 16) {
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const u64 v_lo = v[c].x | ((u64)v[c].y << 32), v_hi = v[c].z | ((u64)v[c].w << 32);
-                for (u32 k = 16 * c; k < n && k < 16u * (c + 1); k++)
-                    d[k] = (u8)((k & 8) ? v_hi >> (8 * (k & 7)) : v_lo >> (8 * (k & 7)));
+                for (int c = 0; c < 4; c++)
+                    if (16u * (c + 1) <= n) {
+                        *(u64_u*)(d + 16 * c) = v[c].x | ((u64)v[c].y << 32);
+                        *(u64_u*)(d + 16 * c + 8) = v[c].z | ((u64)v[c].w << 32);
+                    }
+                if (n & 15) {  // the last 16 bytes once more, from the source
+                    const u32x4 t = load_u128_guarded(rsrc, sp + n - 16, R.len);
+                    *(u64_u*)(d + n - 16) = t.x | ((u64)t.y << 32);
+                    *(u64_u*)(d + n - 8) = t.z | ((u64)t.w << 32);
+                }
+            } else if (n >= 8) {
+                const u32 sh = 8 * (n - 8);  // bytes n-8 .. n-1
+                *(u64_u*)d = v_lo;
+                *(u64_u*)(d + n - 8) = sh ? (v_lo >> sh) | (v_hi << (64 - sh)) : v_lo;
+            } else if (n >= 4) {
+                *(u32_u*)d = (u32)v_lo;
+                *(u32_u*)(d + n - 4) = (u32)(v_lo >> (8 * (n - 4)));
+            } else {
+                for (u32 k = 0; k < n; k++) d[k] = (u8)(v_lo >> (8 * k));
             }
             const u32 a = lo - B, b = hi - B;  // at most 3 bitmap words
             for (u32 w = a >> 5; w <= (b - 1) >> 5; w++) {
@@ -1937,13 +1958,15 @@ __global__ __launch_bounds__(256) void k_snappy_tiles(const u8* __restrict__ src
         w0 = __shfl(w0, 0);
         if (w0 >= last) break;
         const u32 e = w0 + lane;
+        const u32 INF = 0xFFFFFFFFu;
         bool pending = false;
-        u32 o = 0, len = 0, off = 0;
+        u32 o = INF, oe = INF, len = 0, off = 0;  // every lane holds its element's output range, literals too
         if (e < last) {
             const RunRec rr = runs[e];
+            o = rr.out_off;
+            oe = e + 1 < T.cnt ? runs[e + 1].out_off : n_out;
             if (rr.info & 1) {
-                o = rr.out_off;
-                len = (e + 1 < T.cnt ? runs[e + 1].out_off : n_out) - o;
+                len = oe - o;
                 off = rr.info >> 1;
                 pending = true;
                 int bad = 0;
@@ -1960,39 +1983,62 @@ __global__ __launch_bounds__(256) void k_snappy_tiles(const u8* __restrict__ src
         }
         // source bytes [sa, sb) and own bytes [da, db), tile relative
         const u32 da = o - B, db = da + len, sa = da - off, sb = sa + (len < off ? len : off);
+        // The part of the source that lies inside this chunk's own output depends on copies of this wave only:
+        // the outputs of the chunk's elements are consecutive, so the lanes whose output overlaps my source are a
+        // contiguous range (two binary searches over the lanes), and waiting for them is a ballot, not a trip
+        // through the bitmap.  The part in front of the chunk waits for the bitmap as before.
+        const u32 sA = o - off, sB = sA + (len < off ? len : off);
+        u32 c_lo = 0, c_hi = 0;  // lanes with oe <= sA / lanes with o < sB
+        {
+            const u32 v = __shfl(oe, 63), v2 = __shfl(o, 63);
+            if (v <= sA) c_lo = 64;
+            if (v2 < sB) c_hi = 64;
+        }
+        for (u32 st = 32; st > 0; st >>= 1) {
+            const u32 i1 = c_lo + st - 1 < 64 ? c_lo + st - 1 : 63, i2 = c_hi + st - 1 < 64 ? c_hi + st - 1 : 63;
+            const u32 v = __shfl(oe, i1), v2 = __shfl(o, i2);
+            if (c_lo + st - 1 < 64 && v <= sA) c_lo += st;
+            if (c_hi + st - 1 < 64 && v2 < sB) c_hi += st;
+        }
+        u64 wait = 0;
+        if (pending && c_hi > c_lo) wait = (c_hi >= 64 ? ~0ull : (1ull << c_hi) - 1) & ~((1ull << c_lo) - 1);
+        const u32 chunk_lo = __shfl(o, 0) - B;              // tile offset where this chunk's output starts
+        const u32 xb = sb < chunk_lo ? sb : chunk_lo;       // [sa, xb): the source in front of the chunk
+        bool cross = pending && sa < xb;
         u32 spins = 0;
-        while (__any(pending)) {
-            bool ready = false;
-            if (pending) {
-                ready = true;
-                for (u32 w = sa >> 5; w <= (sb - 1) >> 5; w++) {
+        for (;;) {
+            if (cross) {
+                bool fin_ok = true;
+                for (u32 w = sa >> 5; w <= (xb - 1) >> 5; w++) {
                     u32 m = 0xFFFFFFFFu;
                     if (w == sa >> 5) m &= 0xFFFFFFFFu << (sa & 31);
-                    if (w == (sb - 1) >> 5) m &= 0xFFFFFFFFu >> (31 - ((sb - 1) & 31));
-                    ready = ready && (fin[w] & m) == m;
+                    if (w == (xb - 1) >> 5) m &= 0xFFFFFFFFu >> (31 - ((xb - 1) & 31));
+                    fin_ok = fin_ok && (fin[w] & m) == m;
                 }
+                cross = !fin_ok;
             }
+            const u64 pm = __ballot(pending);
+            if (!pm) break;
+            const bool ready = pending && !cross && !(pm & wait);
             if (ready) {
                 __threadfence_block();  // the bits were set after the bytes they stand for
                 // d[k] = d[k - off], byte by byte in the format's terms.  A byte loop in LDS costs a full LDS
-                // round trip per byte, so bytes move 8 at a time (8 reads in flight, then 8 writes).  That needs
-                // a distance of at least 8: an overlapping copy with a shorter offset repeats a pattern of `off`
-                // bytes, and any multiple of `off` is an equally good distance once that many bytes exist.
+                // round trip per byte, so bytes move 8 at a time (LDS reads and writes at any alignment).  That
+                // needs a distance of at least 8: an overlapping copy with a shorter offset repeats a pattern of
+                // `off` bytes, and any multiple of `off` is an equally good distance once that many bytes exist.
                 u8* d = s_o + da;
                 u32 o2 = off, k = 0;
                 if (off < 8) {
                     o2 = off * ((7 + off) / off);
-                    const u32 head = len < o2 - off ? len : o2 - off;
-                    for (; k < head; k++) d[k] = d[(int)k - (int)off];
+                    const u32 hd = len < o2 - off ? len : o2 - off;
+                    for (; k < hd; k++) d[k] = d[(int)k - (int)off];
                 }
-                for (; k + 8 <= len; k += 8) {
-                    u8 t[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) t[j] = d[(int)(k + j) - (int)o2];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) d[k + j] = t[j];
+                const u32 head = k;
+                for (; k + 8 <= len; k += 8) *(u64_u*)(d + k) = *(const u64_u*)(d + (int)k - (int)o2);
+                if (k < len) {  // the last piece overlaps the one before it instead of a byte loop
+                    if (len - head >= 8) *(u64_u*)(d + len - 8) = *(const u64_u*)(d + (int)(len - 8) - (int)o2);
+                    else for (; k < len; k++) d[k] = d[(int)k - (int)o2];
                 }
-                for (; k < len; k++) d[k] = d[(int)k - (int)o2];
                 __threadfence_block();  // bytes before bits
                 mark_range(da, db);
                 pending = false;
@@ -2009,7 +2055,7 @@ __global__ __launch_bounds__(256) void k_snappy_tiles(const u8* __restrict__ src
     // ---- 3. store (R.out is 16-byte aligned, B is a multiple of 64 KiB)
     u8* dst = R.out + B;
     const u32 n = t_hi - B;
-    for (u32 i = tid * 16; i < n; i += 256 * 16) {
+    for (u32 i = tid * 16; i < n; i += SN_THREADS * 16) {
         if (i + 16 <= n) *(u32x4*)(dst + i) = *(const u32x4*)(s_o + i);
         else for (u32 k = i; k < n; k++) dst[k] = s_o[k];
     }
@@ -2324,7 +2370,7 @@ hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_
 hipError_t launch_snappy_tiles(hipStream_t st, const u8* src, const Region* regions, const u32* otile_region, u32 n_otiles,
                                const RunRec* run_tbl, const u32* otile_first_run, const RegionTotal* totals, int* status) {
     if (n_otiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_snappy_tiles, dim3(n_otiles), dim3(256), 0, st, src, regions, otile_region, run_tbl, otile_first_run,
+    hipLaunchKernelGGL(k_snappy_tiles, dim3(n_otiles), dim3(SN_THREADS), 0, st, src, regions, otile_region, run_tbl, otile_first_run,
                        totals, status);
     LAUNCH_CHECK();
     return hipSuccess;
