@@ -4,6 +4,7 @@
 // decode path: without a working HIP device every entry point that needs one fails with PQD_E_HIP.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -53,12 +54,12 @@ struct pqd_plan {
     std::vector<ChunkRec> chunks;
     std::vector<PageRec> pages;
     std::vector<Region> lregions, sregions;
-    std::vector<u32> otile_region;
-    std::vector<u32> ltile_prefix, lotile_prefix, stile_chain_prefix, lgroup_prefix, sgroup_prefix, ssuper_prefix;
+    std::vector<LvTile> lv_order;  // launch order of the level super-tiles
+    std::vector<u32> stile_chain_prefix, sgroup_prefix, ssuper_prefix;
     std::vector<Seg> segs;
     std::vector<u32> seg_blk_prefix;
     std::vector<u32> bool_pages, btile_prefix, row_chunks, rtile_prefix;
-    std::vector<u32> ltile_region, stile_region;  // region of every chain tile
+    std::vector<u32> stile_region;  // region of every string chain tile
     std::vector<OutPtrs> outs;
     std::vector<int> chunk_width;
 
@@ -67,23 +68,22 @@ struct pqd_plan {
     size_t arena_bytes = 0;
     ChunkRec* d_chunks = nullptr; PageRec* d_pages = nullptr;
     Region *d_lregions = nullptr, *d_sregions = nullptr;
-    u32* d_otile_region = nullptr;
-    u32 *d_ltile_prefix = nullptr, *d_lotile_prefix = nullptr, *d_stile_chain_prefix = nullptr;
-    u32 *d_lgroup_prefix = nullptr, *d_sgroup_prefix = nullptr, *d_ssuper_prefix = nullptr;
+    u32* d_stile_chain_prefix = nullptr;
+    u32 *d_sgroup_prefix = nullptr, *d_ssuper_prefix = nullptr;
     Seg* d_segs = nullptr; u32* d_seg_blk_prefix = nullptr;
     u32 *d_bool_pages = nullptr, *d_btile_prefix = nullptr;
     u32 *d_row_chunks = nullptr, *d_rtile_prefix = nullptr;
-    ExitRec *d_lexit = nullptr, *d_sexit = nullptr, *d_lgexit = nullptr, *d_sgexit = nullptr;
-    TileEntry *d_ltile_entry = nullptr, *d_stile_entry = nullptr, *d_lgroup_entry = nullptr, *d_sgroup_entry = nullptr;
-    ChainArgs lchain = {}, schain = {};
-    RegionTotal *d_ltotals = nullptr, *d_stotals = nullptr;
-    RunRec* d_runs = nullptr; u32* d_otile_first = nullptr; u32* d_otile_cnt = nullptr;
+    ExitRec *d_sexit = nullptr, *d_sgexit = nullptr;
+    TileEntry *d_stile_entry = nullptr, *d_sgroup_entry = nullptr;
+    ChainArgs schain = {};
+    LvArgs lv = {};
+    RegionTotal* d_stotals = nullptr;
     PageDyn* d_page_dyn = nullptr; ChunkDyn* d_chunk_dyn = nullptr; RowTile* d_row_tiles = nullptr;
     int* d_status = nullptr;
     u8 *ff_begin = nullptr, *zero_begin = nullptr;  // per-run reset ranges
     size_t ff_bytes = 0, zero_bytes = 0;
 
-    u32 n_ltiles = 0, n_lotiles = 0, n_stiles_chain = 0, n_btiles = 0, n_rtiles = 0, n_copy_blocks = 0;
+    u32 n_lvtiles = 0, n_stiles_chain = 0, n_btiles = 0, n_rtiles = 0, n_copy_blocks = 0;
     int64_t bytes_in = 0, copy_bytes = 0;
 
     // ring of per-run event sets: {run start, run end, value gather start, value gather end}
@@ -119,6 +119,7 @@ int map_status(int st) {
     case 0: return PQD_OK;
     case ST_CORRUPT: return PQD_E_CORRUPT;
     case ST_NONCANONICAL: return PQD_E_NONCANONICAL;
+    case ST_INTERNAL: return PQD_E_HIP;
     default: return PQD_E_UNSUPPORTED;
     }
 }
@@ -335,11 +336,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     }
 
     // regions
-    u64 run_base = 0;
-    pl->ltile_prefix.push_back(0);
-    pl->lotile_prefix.push_back(0);
+    u64 n_lv = 0;
     pl->stile_chain_prefix.push_back(0);
-    pl->lgroup_prefix.push_back(0);
     pl->sgroup_prefix.push_back(0);
     pl->ssuper_prefix.push_back(0);
     pl->btile_prefix.push_back(0);
@@ -365,19 +363,17 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                 R.src_off = payload_off[pi] + l + 4;
                 R.len = nb - 4;
                 R.width = (u32)bits_len((unsigned)(lv == 0 ? C.max_rep : C.max_def));
-                R.tile_base = pl->ltile_prefix.back();
-                R.group_base = pl->lgroup_prefix.back();
-                R.otile_base = pl->lotile_prefix.back();
-                R.run_base = run_base;
+                R.lv_base = (u32)n_lv;
                 R.n_out = P.num_values;
                 R.out = (u8*)(uintptr_t)lvl_off[pi];  // patched with the array base below
                 R.page = pi;
                 R.count_level = lv == 1 ? (u32)C.max_def : ERR_POS;
+                // every block has at least one super-tile: an empty one still has to report its missing values
+                const u32 n_sup = R.len ? (R.len + LV_T - 1) / LV_T : 1;
+                for (u32 t = 0; t < n_sup; t++) pl->lv_order.push_back(LvTile{(u32)pl->lregions.size(), t});
                 pl->lregions.push_back(R);
-                push_prefix(pl->ltile_prefix, (R.len + CH_T - 1) / CH_T, ovf);
-                push_prefix(pl->lgroup_prefix, ((u64)R.len + CH_G_LEVELS * CH_T - 1) / (CH_G_LEVELS * CH_T), ovf);
-                push_prefix(pl->lotile_prefix, ((u64)P.num_values + OT - 1) / OT, ovf);
-                run_base += R.len;
+                n_lv += n_sup;
+                if (n_lv > 0x7fffffffull) ovf = true;
                 l += nb;
             }
             if (C.phys_type == PQD_BYTE_ARRAY) {
@@ -405,15 +401,11 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         }
     }
     if (ovf) return fail(ctx, PQD_E_UNSUPPORTED, "batch too large for 32-bit tile indices");
-    pl->n_ltiles = pl->ltile_prefix.back();
-    pl->n_lotiles = pl->lotile_prefix.back();
-    pl->otile_region.reserve((size_t)pl->n_lotiles + 1);
-    for (size_t r = 0; r < pl->lregions.size(); r++)
-        pl->otile_region.insert(pl->otile_region.end(), pl->lotile_prefix[r + 1] - pl->lotile_prefix[r], (u32)r);
-    pl->otile_region.push_back(ERR_POS);  // spare entry: the tile after the last belongs to no region
+    pl->n_lvtiles = (u32)n_lv;
+    // workgroups take super-tiles in this order: super-tile t of every block before super-tile t + 1 of any, so
+    // the one a workgroup waits for was always taken earlier, and the chains of all blocks advance side by side
+    std::stable_sort(pl->lv_order.begin(), pl->lv_order.end(), [](const LvTile& x, const LvTile& y) { return x.index < y.index; });
     pl->n_stiles_chain = pl->stile_chain_prefix.back();
-    for (size_t r = 0; r < pl->lregions.size(); r++)
-        pl->ltile_region.insert(pl->ltile_region.end(), pl->ltile_prefix[r + 1] - pl->ltile_prefix[r], (u32)r);
     for (size_t r = 0; r < pl->sregions.size(); r++)
         pl->stile_region.insert(pl->stile_region.end(), pl->stile_chain_prefix[r + 1] - pl->stile_chain_prefix[r], (u32)r);
     pl->n_btiles = pl->btile_prefix.back();
@@ -424,12 +416,9 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_pages = ap.take(n_pages * sizeof(PageRec));
     const size_t o_lreg = ap.take(pl->lregions.size() * sizeof(Region));
     const size_t o_sreg = ap.take(pl->sregions.size() * sizeof(Region));
-    const size_t o_ltp = ap.take(pl->ltile_prefix.size() * 4);
-    const size_t o_lotp = ap.take(pl->lotile_prefix.size() * 4);
-    const size_t o_otr = ap.take(pl->otile_region.size() * 4);
+    const size_t o_lvo = ap.take(pl->lv_order.size() * sizeof(LvTile));
     const size_t o_sctp = ap.take(pl->stile_chain_prefix.size() * 4);
-    const size_t o_ltr = ap.take(pl->ltile_region.size() * 4), o_str = ap.take(pl->stile_region.size() * 4);
-    const size_t o_lgp = ap.take(pl->lgroup_prefix.size() * 4);
+    const size_t o_str = ap.take(pl->stile_region.size() * 4);
     const size_t o_sgp = ap.take(pl->sgroup_prefix.size() * 4);
     const size_t o_ssp = ap.take(pl->ssuper_prefix.size() * 4);
     const size_t o_bp = ap.take(pl->bool_pages.size() * 4);
@@ -437,37 +426,31 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_rc = ap.take(pl->row_chunks.size() * 4);
     const size_t o_rtp = ap.take(pl->rtile_prefix.size() * 4);
     // scratch
-    const size_t o_lexit = ap.take((size_t)pl->n_ltiles * CH_E_LEVELS * sizeof(ExitRec));
     const size_t o_sexit = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * sizeof(StrExit));
     const size_t o_scp = ap.take((size_t)pl->n_stiles_chain * CH_THREADS * 16);
     const size_t o_smap = ap.take((size_t)pl->n_stiles_chain * (CH_T / 8) * 2);
     const size_t o_scand = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * 2);
     const size_t o_sncand = ap.take((size_t)pl->n_stiles_chain * 2), o_sgpre = ap.take((size_t)pl->n_stiles_chain * 2);
     const size_t o_sspre = ap.take((size_t)pl->n_stiles_chain * 2);
-    const u32 n_lgroups = pl->lgroup_prefix.back(), n_sgroups = pl->sgroup_prefix.back();
-    const size_t o_lgexit = ap.take((size_t)n_lgroups * CH_E_LEVELS * sizeof(ExitRec));
+    const u32 n_sgroups = pl->sgroup_prefix.back();
     const size_t o_sgexit = ap.take((size_t)n_sgroups * CH_E_STRINGS * sizeof(ExitRec));
     const u32 n_ssupers = pl->ssuper_prefix.back();
     const size_t o_ssexit = ap.take((size_t)n_ssupers * CH_E_STRINGS * sizeof(ExitRec));
-    const size_t o_ltot = ap.take(pl->lregions.size() * sizeof(RegionTotal));
     const size_t o_stot = ap.take(pl->sregions.size() * sizeof(RegionTotal));
-    const size_t o_runs = ap.take((size_t)run_base * sizeof(RunRec));
     const size_t o_rtiles = ap.take((size_t)pl->n_rtiles * sizeof(RowTile));
-    const size_t o_otc = ap.take((size_t)pl->n_lotiles * 4);
     const size_t o_cdyn = ap.take(n_chunks * sizeof(ChunkDyn));
     // reset to 0xFF every run
     const size_t o_ff = ap.total;
-    const size_t o_lte = ap.take((size_t)pl->n_ltiles * sizeof(TileEntry));
     const size_t o_ste = ap.take((size_t)pl->n_stiles_chain * sizeof(TileEntry));
-    const size_t o_lge = ap.take((size_t)n_lgroups * sizeof(TileEntry));
     const size_t o_sge = ap.take((size_t)n_sgroups * sizeof(TileEntry));
     const size_t o_sse = ap.take((size_t)n_ssupers * sizeof(TileEntry));
-    const size_t o_otf = ap.take(((size_t)pl->n_lotiles + 1) * 4);  // one spare entry
     const size_t ff_end = ap.total;
     // reset to 0 every run
     const size_t o_zero = ap.total;
     const size_t o_pdyn = ap.take(n_pages * sizeof(PageDyn));
     const size_t o_status = ap.take(16);
+    const size_t o_lvticket = ap.take(16);
+    const size_t o_lvpos = ap.take((size_t)pl->n_lvtiles * 8), o_lvval = ap.take((size_t)pl->n_lvtiles * 8);  // hand-off granules
     const size_t zero_end = ap.total;
     // the copy segment tables depend on output addresses → placed last, sized now
     size_t n_segs = 0;
@@ -527,33 +510,28 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
 
     pl->d_chunks = (ChunkRec*)(A + o_chunks); pl->d_pages = (PageRec*)(A + o_pages);
     pl->d_lregions = (Region*)(A + o_lreg); pl->d_sregions = (Region*)(A + o_sreg);
-    pl->d_ltile_prefix = (u32*)(A + o_ltp); pl->d_lotile_prefix = (u32*)(A + o_lotp);
     pl->d_stile_chain_prefix = (u32*)(A + o_sctp);
-    pl->d_lgroup_prefix = (u32*)(A + o_lgp); pl->d_sgroup_prefix = (u32*)(A + o_sgp);
+    pl->d_sgroup_prefix = (u32*)(A + o_sgp);
     pl->d_ssuper_prefix = (u32*)(A + o_ssp);
-    pl->d_lgexit = (ExitRec*)(A + o_lgexit); pl->d_sgexit = (ExitRec*)(A + o_sgexit);
-    pl->d_lgroup_entry = (TileEntry*)(A + o_lge); pl->d_sgroup_entry = (TileEntry*)(A + o_sge);
+    pl->d_sgexit = (ExitRec*)(A + o_sgexit);
+    pl->d_sgroup_entry = (TileEntry*)(A + o_sge);
     pl->d_bool_pages = (u32*)(A + o_bp); pl->d_btile_prefix = (u32*)(A + o_btp);
     pl->d_row_chunks = (u32*)(A + o_rc); pl->d_rtile_prefix = (u32*)(A + o_rtp);
-    pl->d_lexit = (ExitRec*)(A + o_lexit); pl->d_sexit = (ExitRec*)(A + o_sexit);
-    pl->d_ltotals = (RegionTotal*)(A + o_ltot); pl->d_stotals = (RegionTotal*)(A + o_stot);
-    pl->d_runs = (RunRec*)(A + o_runs); pl->d_row_tiles = (RowTile*)(A + o_rtiles);
+    pl->d_sexit = (ExitRec*)(A + o_sexit);
+    pl->d_stotals = (RegionTotal*)(A + o_stot);
+    pl->d_row_tiles = (RowTile*)(A + o_rtiles);
     pl->d_chunk_dyn = (ChunkDyn*)(A + o_cdyn);
-    pl->d_ltile_entry = (TileEntry*)(A + o_lte); pl->d_stile_entry = (TileEntry*)(A + o_ste);
-    pl->d_otile_first = (u32*)(A + o_otf);
-    pl->d_otile_region = (u32*)(A + o_otr);
-    pl->d_otile_cnt = (u32*)(A + o_otc);
+    pl->d_stile_entry = (TileEntry*)(A + o_ste);
     pl->d_page_dyn = (PageDyn*)(A + o_pdyn); pl->d_status = (int*)(A + o_status);
     pl->d_segs = (Seg*)(A + o_segs); pl->d_seg_blk_prefix = (u32*)(A + o_segp);
     pl->ff_begin = A + o_ff; pl->ff_bytes = ff_end - o_ff;
     pl->zero_begin = A + o_zero; pl->zero_bytes = zero_end - o_zero;
 
-    pl->lchain = ChainArgs{pl->d_lregions, pl->d_ltile_prefix, pl->d_lgroup_prefix, (u32)pl->lregions.size(), pl->n_ltiles, n_lgroups,
-                           pl->d_lexit, pl->d_lgexit, pl->d_ltile_entry, pl->d_lgroup_entry, pl->d_ltotals};
+    pl->lv = LvArgs{pl->d_lregions, (const LvTile*)(A + o_lvo), pl->n_lvtiles, (u64*)(A + o_lvpos), (u64*)(A + o_lvval),
+                    (u32*)(A + o_lvticket), pl->d_page_dyn, pl->d_status};
     pl->schain = ChainArgs{pl->d_sregions, pl->d_stile_chain_prefix, pl->d_sgroup_prefix, (u32)pl->sregions.size(), pl->n_stiles_chain,
                            n_sgroups, pl->d_sexit, pl->d_sgexit, pl->d_stile_entry, pl->d_sgroup_entry, pl->d_stotals, A + o_scp,
                            (u32*)(A + o_ssp), n_ssupers, (ExitRec*)(A + o_ssexit), (TileEntry*)(A + o_sse)};
-    pl->lchain.tile_region = (u32*)(A + o_ltr);
     pl->schain.tile_region = (u32*)(A + o_str);
     pl->schain.str_index = StrIndex{(const unsigned short*)(A + o_smap), (const unsigned short*)(A + o_scand),
                                     (const unsigned short*)(A + o_sncand), (unsigned short*)(A + o_sgpre), (unsigned short*)(A + o_sspre)};
@@ -563,13 +541,9 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if ((rc = upload(ctx, pl->d_pages, pl->pages))) return rc;
     if ((rc = upload(ctx, pl->d_lregions, pl->lregions))) return rc;
     if ((rc = upload(ctx, pl->d_sregions, pl->sregions))) return rc;
-    if ((rc = upload(ctx, pl->d_ltile_prefix, pl->ltile_prefix))) return rc;
-    if ((rc = upload(ctx, pl->d_lotile_prefix, pl->lotile_prefix))) return rc;
-    if ((rc = upload(ctx, pl->d_otile_region, pl->otile_region))) return rc;
+    if ((rc = upload(ctx, (LvTile*)(A + o_lvo), pl->lv_order))) return rc;
     if ((rc = upload(ctx, pl->d_stile_chain_prefix, pl->stile_chain_prefix))) return rc;
-    if ((rc = upload(ctx, (u32*)(A + o_ltr), pl->ltile_region))) return rc;
     if ((rc = upload(ctx, (u32*)(A + o_str), pl->stile_region))) return rc;
-    if ((rc = upload(ctx, pl->d_lgroup_prefix, pl->lgroup_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_sgroup_prefix, pl->sgroup_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_ssuper_prefix, pl->ssuper_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_bool_pages, pl->bool_pages))) return rc;
@@ -596,7 +570,7 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     hipStream_t st = ctx->stream;
     const u32 n_chunks = (u32)pl->chunks.size(), n_pages = (u32)pl->pages.size();
     const u32 n_lreg = (u32)pl->lregions.size(), n_sreg = (u32)pl->sregions.size();
-    if (pl->n_ltiles + pl->n_stiles_chain + pl->n_lotiles)
+    if (pl->n_stiles_chain)
         HIP_TRY(ctx, hipMemsetAsync(pl->ff_begin, 0xFF, pl->ff_bytes, st));
     HIP_TRY(ctx, hipMemsetAsync(pl->zero_begin, 0, pl->zero_bytes, st));
 
@@ -621,12 +595,7 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     if (side) HIP_TRY(ctx, hipEventRecord(pl->ev_join, cst));
 
     // levels
-    if (n_lreg) {
-        HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, src, pl->lchain, pl->d_runs, pl->d_otile_first, pl->d_page_dyn, pl->d_status, 0));
-        HIP_TRY(ctx, launch_chain(st, KIND_LEVELS, src, pl->lchain, pl->d_runs, pl->d_otile_first, pl->d_page_dyn, pl->d_status, 1));
-        HIP_TRY(ctx, launch_levels_expand(st, 1, src, pl->d_lregions, pl->d_otile_region, pl->d_lotile_prefix, n_lreg, pl->n_lotiles, pl->d_runs,
-                                          pl->d_otile_first, pl->d_ltotals, pl->d_otile_cnt, pl->d_page_dyn));
-    }
+    if (n_lreg) HIP_TRY(ctx, launch_levels(st, src, pl->lv));
     HIP_TRY(ctx, launch_page_scan(st, pl->d_chunks, n_chunks, pl->d_pages, n_pages, pl->d_page_dyn, pl->d_chunk_dyn, pl->d_status));
     HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, (u32)pl->bool_pages.size(), pl->n_btiles,
                               pl->d_chunks, pl->d_page_dyn));

@@ -15,7 +15,7 @@ constexpr u32 UNKNOWN_POS = 0xFFFFFFFEu;  // group exit not tabulated
 constexpr u32 NO_SLOT = 0xFFFFFFFFu;      // an entry without a row in the exit table
 
 // device status codes (mapped to pqd_status by the host)
-constexpr int ST_CORRUPT = 1, ST_NONCANONICAL = 2, ST_UNSUPPORTED = 3;
+constexpr int ST_CORRUPT = 1, ST_NONCANONICAL = 2, ST_UNSUPPORTED = 3, ST_INTERNAL = 4;  // INTERNAL: a workgroup gave up waiting for another
 
 // parquet physical types
 constexpr int PT_BOOLEAN = 0, PT_BYTE_ARRAY = 6;
@@ -68,7 +68,7 @@ struct Region {
     u32 page;        // page index
     u32 count_level; // levels: count values equal to this into page_dyn[page].nn; ERR_POS = do not count
     u32 group_base;  // first hop group of the region in the global group numbering
-    u32 pad;
+    u32 lv_base;     // levels, single-pass decode: first super-tile of the region in the granule numbering
 };
 
 struct ExitRec { u32 tgt; u32 cnt; u64 vals; };
@@ -141,6 +141,27 @@ hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs
 hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_region,
                                 const u32* otile_prefix, u32 n_regions, u32 n_otiles, const RunRec* run_tbl,
                                 const u32* otile_first_run, const RegionTotal* totals, u32* otile_cnt, PageDyn* page_dyn);
+// ---- single-pass level decode of the page path (pqd_levels.hip) ---------------------------------
+// A super-tile is LV_T chain bytes of one level block and belongs to one workgroup, which resolves the run
+// headers inside it, learns where the true chain enters from the super-tile before it (one 8-byte granule per
+// boundary), and expands its runs straight into the level array.
+constexpr u32 LV_T = 8192;        // chain bytes per super-tile
+constexpr u32 LV_THREADS = 512;   // one 16-byte sub-tile per thread
+constexpr u32 LV_SUB = LV_T / LV_THREADS;
+constexpr u32 LV_SPIN_MAX = 1u << 22;  // polls of a granule before a workgroup gives up (safety net, never reached)
+struct LvTile { u32 region, index; };  // launch order: super-tile `index` of `region`; predecessors come first
+struct LvArgs {
+    const Region* regions;
+    const LvTile* order;   // n_tiles entries sorted by (index, region)
+    u32 n_tiles;
+    u64* pos_g;            // n_tiles granules {1 << 32 | exit position}; zero before every launch
+    u64* val_g;            // n_tiles granules {1 << 32 | values up to the super-tile's end, saturated}; zero before every launch
+    u32* ticket;           // one word, zero before every launch
+    PageDyn* page_dyn;     // nn of the counted regions' pages is added to (zero before every launch); may be null
+    int* status;
+};
+hipError_t launch_levels(hipStream_t st, const u8* src, const LvArgs& a);
+
 hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks, const PageRec* pages, u32 n_pages,
                             PageDyn* page_dyn, ChunkDyn* chunk_dyn, int* status);
 hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids, const u32* btile_prefix,
