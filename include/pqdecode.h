@@ -147,6 +147,11 @@ const void* pqd_plan_device_ptr(pqd_plan* plan, size_t chunk, pqd_output which);
  * (>= 0) or a negative status. */
 int64_t pqd_plan_fetch(pqd_plan* plan, size_t chunk, pqd_output which, void* dst, size_t cap);
 
+/* Diagnostics: when the plan was created with PQD_LV_STAMPS set in the environment, the level kernel of the
+ * last run left 16 wall-clock stamps (100 MHz) per workgroup; copies them to `dst` and returns the bytes
+ * (0 when the plan has none). */
+int64_t pqd_plan_debug_stamps(pqd_plan* plan, void* dst, size_t cap);
+
 /* Convenience: host buffer in, results on device; = copy_to_device + plan_create + run + sync.
  * The plan owns the device copy of `src`. */
 int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,

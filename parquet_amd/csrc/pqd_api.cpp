@@ -439,6 +439,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_stot = ap.take(pl->sregions.size() * sizeof(RegionTotal));
     const size_t o_rtiles = ap.take((size_t)pl->n_rtiles * sizeof(RowTile));
     const size_t o_cdyn = ap.take(n_chunks * sizeof(ChunkDyn));
+    const bool lv_stamps = getenv("PQD_LV_STAMPS") != nullptr;  // diagnostics: per-workgroup phase stamps of k_levels
+    const size_t o_lvst = lv_stamps ? ap.take((size_t)pl->n_lvtiles * LV_STAMPS * 8) : 0;
     // reset to 0xFF every run
     const size_t o_ff = ap.total;
     const size_t o_ste = ap.take((size_t)pl->n_stiles_chain * sizeof(TileEntry));
@@ -528,7 +530,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->zero_begin = A + o_zero; pl->zero_bytes = zero_end - o_zero;
 
     pl->lv = LvArgs{pl->d_lregions, (const LvTile*)(A + o_lvo), pl->n_lvtiles, (u64*)(A + o_lvpos), (u64*)(A + o_lvval),
-                    (u32*)(A + o_lvticket), pl->d_page_dyn, pl->d_status};
+                    (u32*)(A + o_lvticket), pl->d_page_dyn, pl->d_status, lv_stamps ? (u64*)(A + o_lvst) : nullptr};
     pl->schain = ChainArgs{pl->d_sregions, pl->d_stile_chain_prefix, pl->d_sgroup_prefix, (u32)pl->sregions.size(), pl->n_stiles_chain,
                            n_sgroups, pl->d_sexit, pl->d_sgexit, pl->d_stile_entry, pl->d_sgroup_entry, pl->d_stotals, A + o_scp,
                            (u32*)(A + o_ssp), n_ssupers, (ExitRec*)(A + o_ssexit), (TileEntry*)(A + o_sse)};
@@ -747,6 +749,15 @@ int64_t pqd_plan_fetch(pqd_plan* pl, size_t c, pqd_output which, void* dst, size
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(dst, p, n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return (int64_t)n;
+}
+
+int64_t pqd_plan_debug_stamps(pqd_plan* pl, void* dst, size_t cap) {
+    if (!pl || !pl->lv.stamps) return 0;
+    const size_t n = (size_t)pl->n_lvtiles * LV_STAMPS * 8;
+    if (n > cap || !dst) return PQD_E_ARG;
+    HIP_TRY(pl->ctx, hipSetDevice(pl->ctx->device));
+    HIP_TRY(pl->ctx, hipMemcpy(dst, pl->lv.stamps, n, hipMemcpyDeviceToHost));
     return (int64_t)n;
 }
 

@@ -159,7 +159,9 @@ struct LvArgs {
     u32* ticket;           // one word, zero before every launch
     PageDyn* page_dyn;     // nn of the counted regions' pages is added to (zero before every launch); may be null
     int* status;
+    u64* stamps;           // diagnostics only (else null): LV_STAMPS wall-clock stamps (100 MHz) per ticket
 };
+constexpr u32 LV_STAMPS = 16;
 hipError_t launch_levels(hipStream_t st, const u8* src, const LvArgs& a);
 
 hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks, const PageRec* pages, u32 n_pages,

@@ -40,13 +40,18 @@ constexpr u32 LV_GROUP = 256;                   // bytes per hop group
 constexpr u32 LV_GSUB = LV_GROUP / LV_SUB;      // sub-tiles per group
 constexpr u32 LV_NGROUPS = LV_T / LV_GROUP;
 constexpr u32 LV_TC = 512;                      // tabulated entries of a super-tile: its first LV_TC bytes
-constexpr u32 LV_MAXRUNS = LV_T / 2;            // a run that holds values takes at least 2 bytes (width >= 1)
+constexpr u32 LV_SLOTS = LV_SUB / 2;            // runs with values that can start in one sub-tile: each takes at least 2 bytes (width >= 1)
+constexpr u32 LV_DENSE_BITS = 65536;            // bits of the dense level stream per expand window
+constexpr u32 LV_DENSE_BIAS = 128;              // the stream starts at this bit: a block may begin up to 15 values before the window
+constexpr u32 LV_DENSE_WORDS = LV_DENSE_BIAS / 32 + LV_DENSE_BITS / 32 + 6;
+constexpr u32 LV_SEG_SERIAL = 32;               // a run that covers more stream words than this is written by its whole wave
 constexpr u32 LV_WAVES = LV_THREADS / 64;
 constexpr u32 LV_TAIL_MAX = 4096;               // bit-packed values past NumValues that are still examined
 static_assert(LV_SUB == 16, "window loads, memo index and group rounds assume 16-byte sub-tiles");
 static_assert(LV_GSUB * 4 == 64, "one wave = four groups in the group rounds");
 static_assert(LV_TC <= LV_THREADS, "one thread per tabulated entry");
-static_assert(2 * LV_MEMO * 2 >= (LV_MAXRUNS + 1) * 4 + 16 + LV_MAXRUNS * 4, "the run list reuses the memo tables");
+static_assert(2 * LV_MEMO * 2 >= LV_SLOTS * LV_THREADS * 4 + ((LV_DENSE_WORDS + 3) & ~3u) * 4 + LV_T + 8,
+              "run slots, the dense stream and the byte image reuse the memo tables");
 
 static __device__ __forceinline__ u32 lv_idx(u32 rel) { return (rel & (LV_SUB - 1)) * LV_PITCH + (rel >> 4); }
 
@@ -55,6 +60,23 @@ static __device__ __forceinline__ u32 lv_win32(const u32 (&w)[6], int k) {
     const int d = k >> 2, sh = (k & 3) * 8;
     return sh ? (w[d] >> sh) | (w[d + 1] << (32 - sh)) : w[d];
 }
+// The sweep's step: where the run whose header starts at p ends, for headers of at most 4 bytes (runs of fewer
+// than 2^27 values or groups): the same answer as rle_step_w32, with LV_NEEDS_PRECISE for a longer header.
+constexpr u32 LV_NEEDS_PRECISE = 0xFFFFFFFEu;
+static __device__ __forceinline__ u32 lv_next_fast(u32 lo, u32 p, u32 L, u32 w) {
+    const u32 s = ~lo & 0x80808080u;                                  // the stop bits
+    const u32 n = ((u32)__builtin_ctz(s | 0x80000000u) >> 3) + 1;     // header bytes
+    const u32 a = lo & (s ^ (s - 1));                                 // the header's bytes
+    const u32 h = (a & 0x7F) | ((a >> 1) & 0x3F80) | ((a >> 2) & 0x1FC000) | ((a >> 3) & 0xFE00000);
+    const u32 q = p + n, cnt = h >> 1, bw = (w + 7) >> 3;
+    const bool bp = (h & 1) != 0;
+    const u32 prod = w * cnt;                                         // < 2^30
+    const u32 bp_nxt = prod >= L - q ? L : q + prod;
+    bool bad = n > L - p;                                             // header cut off by the block end
+    bad = bad | (bp ? ((w != 0) & (q >= L)) : (bw > L - q));          // io.EOF on the packed bytes / on the value
+    return s == 0 ? LV_NEEDS_PRECISE : bad ? ERR_POS : bp ? bp_nxt : q + bw;
+}
+
 // bytes k..k+7 and byte k+8 of the window for a run-time k in [0, 16)
 static __device__ __forceinline__ void lv_win_dyn(const u32 (&w)[6], u32 k, u32& lo, u32& hi, u32& b8) {
     const u32 d = k >> 2, sh = (k & 3) * 8;
@@ -81,6 +103,42 @@ static __device__ __forceinline__ void lv_run(const u32 (&w)[6], u32 k, u32 q, u
     } else if (width == 0) info = 0;  // width 0 bit-packed groups are runs of zeros
 }
 
+// 16 consecutive values (one per result byte) of the dense stream dn (W bits per value), starting at bit `bit`
+template <int W>
+static __device__ __forceinline__ u32x4 lv_dense16_w(const u32* dn, u32 bit) {
+    constexpr int NX = (16 * W + 31) / 32;
+    const u32 d = bit >> 5, sh = bit & 31;
+    u32 raw[NX + 1], x[NX + 1];
+#pragma unroll
+    for (int k = 0; k <= NX; k++) raw[k] = dn[d + k];
+#pragma unroll
+    for (int k = 0; k < NX; k++) x[k] = __builtin_amdgcn_alignbit(raw[k + 1], raw[k], sh);
+    x[NX] = 0;
+    u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int b = k * W, q = b >> 5, r = b & 31;
+        u32 v;
+        if (r + W <= 32) v = (x[q] >> r) & ((1u << W) - 1);
+        else v = __builtin_amdgcn_alignbit(x[q + 1], x[q], r) & ((1u << W) - 1);
+        o[k >> 2] |= v << (8 * (k & 3));
+    }
+    return u32x4{o[0], o[1], o[2], o[3]};
+}
+static __device__ __forceinline__ u32x4 lv_dense16(const u32* dn, u32 bit, u32 w) {
+    switch (w) {
+    case 0: return u32x4{0, 0, 0, 0};
+    case 1: return lv_dense16_w<1>(dn, bit);
+    case 2: return lv_dense16_w<2>(dn, bit);
+    case 3: return lv_dense16_w<3>(dn, bit);
+    case 4: return lv_dense16_w<4>(dn, bit);
+    case 5: return lv_dense16_w<5>(dn, bit);
+    case 6: return lv_dense16_w<6>(dn, bit);
+    case 7: return lv_dense16_w<7>(dn, bit);
+    default: return lv_dense16_w<8>(dn, bit);
+    }
+}
+
 // 0x80 in every byte of x that is zero
 static __device__ __forceinline__ u64 lv_zero_bytes(u64 x) {
     return ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) & 0x8080808080808080ull;
@@ -98,16 +156,16 @@ static __device__ __forceinline__ void lv_publish(u64* g, u32 v) {
     __hip_atomic_store(g, (1ull << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#define LV_STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(u64)ticket * LV_STAMPS + (i)] = wall_clock64(); } while (0)
+
 __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ src_base, const LvArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short s_memo[2 * LV_MEMO];  // sweep memo | group memo; later the run list
     __shared__ unsigned short s_tc[LV_TC], s_entry[LV_THREADS], s_gentry[LV_NGROUPS];
-    __shared__ u32 s_wn[LV_WAVES], s_wc[LV_WAVES];
+    __shared__ u32 s_wc[LV_WAVES];
     __shared__ u64 s_wv[LV_WAVES];
-    __shared__ u32 s_ticket, s_e, s_ex, s_prefix, s_bad;
+    __shared__ u32 s_ticket, s_e, s_ex, s_prefix, s_bad, s_fill;
     unsigned short* const memo0 = s_memo;
     unsigned short* const la = s_memo + LV_MEMO;
-    u32* const s_out = (u32*)s_memo;                                  // LV_MAXRUNS + 1 run starts
-    u32* const s_info = (u32*)s_memo + ((LV_MAXRUNS + 1 + 3) & ~3u);  // LV_MAXRUNS run records
 
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_ticket = atomicAdd(a.ticket, 1u);
@@ -116,6 +174,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     __syncthreads();
     const u32 ticket = s_ticket;
     if (ticket >= a.n_tiles) return;
+    LV_STAMP(0);
     const LvTile ot = a.order[ticket];
     const Region R = a.regions[ot.region];
     const u32 L = R.len, width = R.width, j = ot.index;
@@ -145,22 +204,23 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
         }
     }
 
+    LV_STAMP(1);
     // ---- 1. sweep: where the chain of every start leaves my 16 bytes
 #pragma unroll
     for (int k = (int)LV_SUB - 1; k >= 0; k--) {
         const u32 p = sub_lo + k;
-        u32 nxt, vals, info;
-        rle_step_w32(lv_win32(w, k), lv_win32(w, k + 4), p, L, width, nxt, vals, info);
+        const u32 nxt = lv_next_fast(lv_win32(w, k), p, L, width);
         const bool valid = p < L;
         const bool in = valid & (nxt < sub_hi) & (nxt < L);  // lands on a later start of mine: its answer is final
         const u32 mi = (u32)k * LV_PITCH + tid;
         const u32 mj = in ? (nxt - sub_lo) * LV_PITCH + tid : mi;
         const u32 t2 = memo0[mj];
         const u32 d = nxt - sb;
-        u32 enc = nxt == ERR_POS ? LV_ERR : d >= LV_FAR ? LV_FAR : d;
+        u32 enc = nxt == ERR_POS ? LV_ERR : d >= LV_FAR ? LV_FAR : d;  // LV_NEEDS_PRECISE is far away too
         if (!valid) enc = LV_ERR;
         memo0[mi] = (unsigned short)(in ? t2 : enc);
     }
+    LV_STAMP(2);
     // ---- 2. groups: a wave owns 1 KiB = 4 groups; round s settles the starts of sub-tile s of every group
     // (lane = group * 16 + start).  Only this wave touches these entries: no workgroup barrier between rounds.
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -177,6 +237,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    LV_STAMP(3);
     // ---- 3. exits of the super-tile for its first LV_TC starts
     if (tid < LV_TC) {
         u32 p = tid;
@@ -210,6 +271,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
         return p;
     };
 
+    LV_STAMP(4);
     // ---- 4. hand-off: entry from the super-tile before, exit to the one after; 5a. group entries
     if (tid == 0) {
         u32 e = 0;
@@ -232,7 +294,9 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
                 ex = p;
             }
         }
+        LV_STAMP(5);
         lv_publish(a.pos_g + R.lv_base + j, ex);
+        LV_STAMP(6);
         if (timeout) set_status(a.status, ST_INTERNAL, ot.region);
         else if (ex == ERR_POS && e != ERR_POS) set_status(a.status, ST_CORRUPT, ot.region);
         s_e = e;
@@ -250,6 +314,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     if (ex == ERR_POS) return;  // the chain failed in this block: status is set, nothing more is written
     const bool active = e < se && e < L;  // the true chain starts at least one run here
 
+    LV_STAMP(7);
     // ---- 5b. sub-tile entries: one lane per group
     if (active && tid < LV_NGROUPS) {
         const u32 r = s_gentry[tid];
@@ -264,7 +329,18 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     }
     __syncthreads();
 
-    // ---- 6. values: runs that hold values and the values of all runs that start in my 16 bytes
+    LV_STAMP(8);
+    // ---- 6. values: every thread parses the true runs that start in its 16 bytes once and keeps those that
+    // hold values in slots of its own (the memo tables are dead: their last readers ran before the barrier
+    // above).  A slot is 32 bits: values (0xFFFF: 65535 or more, parsed again where needed) | how to produce them:
+    //   RLE         (value << 1 | header offset in the sub-tile << 9) << 16
+    //   bit-packed  (1 | offset of the packed bytes from the sub-tile start << 1 | header offset << 6) << 16
+    // The super-tile's bytes go to LDS as well: the packed bytes are read from there when the stream is assembled.
+    u32* const sl = (u32*)s_memo;                               // [LV_SLOTS][LV_THREADS]
+    u32* const dense = sl + LV_SLOTS * LV_THREADS;              // LV_DENSE_WORDS
+    u32* const img = dense + ((LV_DENSE_WORDS + 3) & ~3u);      // LV_T / 4 + 2 words: the super-tile and 8 bytes behind it
+    *(u32x4*)(img + tid * 4) = u32x4{w[0], w[1], w[2], w[3]};
+    if (tid == LV_THREADS - 1) { img[LV_T / 4] = w[4]; img[LV_T / 4 + 1] = w[5]; }
     const u32 my_entry = active ? s_entry[tid] : 0xFFFF;
     u32 n_runs = 0;
     u64 n_vals = 0;
@@ -273,28 +349,41 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
         while (q < sub_hi && q < L) {
             u32 nxt, vals, info;
             lv_run(w, q - sub_lo, q, L, width, nxt, vals, info);
-            n_runs += vals != 0;
+            if (vals && width && n_runs < LV_SLOTS) {  // a run with values is at least 2 bytes: never more than LV_SLOTS
+                const u32 qo = q - sub_lo;
+                const u32 how = (info & 1) ? (1u | (((info >> 1) - sub_lo) << 1) | (qo << 6)) : (info | (qo << 9));
+                sl[n_runs * LV_THREADS + tid] = (vals < 0xFFFFu ? vals : 0xFFFFu) | (how << 16);
+                n_runs++;
+            }
             n_vals += vals;
             q = nxt;  // never ERR_POS: the exit of the super-tile is known to be good
         }
     }
-    u32 sn = n_runs;
     u64 sv = n_vals;
     for (int d = 1; d < 64; d <<= 1) {
-        const u32 tn = __shfl_up(sn, d);
         const u64 tv = __shfl_up(sv, d);
-        if (lane >= (u32)d) { sn += tn; sv += tv; }
+        if (lane >= (u32)d) sv += tv;
     }
-    if (lane == 63) { s_wn[wv] = sn; s_wv[wv] = sv; }
+    if (lane == 63) s_wv[wv] = sv;
     __syncthreads();
-    u32 base_n = 0, tot_n = 0;
     u64 base_v = 0, tot_v = 0;
 #pragma unroll
     for (u32 q = 0; q < LV_WAVES; q++) {
-        if (q < wv) { base_n += s_wn[q]; base_v += s_wv[q]; }
-        tot_n += s_wn[q];
+        if (q < wv) base_v += s_wv[q];
         tot_v += s_wv[q];
     }
+    // slot i of this thread: the run's values and (RLE) value << 1 or (bit-packed) offset of the packed bytes << 1 | 1
+    auto slot = [&](u32 i, u32& vals, u32& info) {
+        const u32 x = sl[i * LV_THREADS + tid], how = x >> 16;
+        vals = x & 0xFFFF;
+        info = (how & 1) ? (how & 0x3F) : (how & 0x1FF);
+        if (vals == 0xFFFF) {  // a long run: its count comes from the header once more
+            const u32 qo = (how & 1) ? (how >> 6) & 15 : (how >> 9) & 15;
+            u32 nxt, inf;
+            lv_run(w, qo, sub_lo + qo, L, width, nxt, vals, inf);
+        }
+    };
+    LV_STAMP(9);
     if (tid == 0) {
         u32 prefix = 0;
         bool timeout = false;
@@ -303,114 +392,187 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
             timeout = !(x >> 32);
             prefix = (u32)x;
         }
+        LV_STAMP(10);
         const u64 incl = (u64)prefix + tot_v;
         lv_publish(a.val_g + R.lv_base + j, incl < 0xFFFFFFFFull ? (u32)incl : 0xFFFFFFFFu);
         if (timeout) set_status(a.status, ST_INTERNAL, ot.region);
         else if (last && incl < n_out) set_status(a.status, ST_CORRUPT, ot.region);  // defs[:NumValues] out of range
         s_prefix = prefix;
         s_bad = 0;
+        s_fill = 0;
     }
     __syncthreads();
     if (!active) return;
     const u32 prefix = s_prefix;
-    const u64 end64 = (u64)prefix + tot_v;
-    const u32 o_lo = prefix < n_out ? prefix : n_out, o_hi = end64 < n_out ? (u32)end64 : n_out;
+    const u64 my_first = base_v + sv - n_vals;  // local index (within the super-tile's values) of my first run's first value
+    const bool counting = R.count_level != ERR_POS;
+    LV_STAMP(11);
 
-    // ---- 7a. the run list (the memo tables are dead: their last readers ran before the barriers above)
-    u32 m;
-    if (width == 0) {  // every value is 0: one run covers the super-tile's part
-        m = 1;
-        if (tid == 0) { s_out[0] = o_lo; s_info[0] = 0; s_out[1] = o_hi; }
-    } else {
-        m = tot_n;
-        if (my_entry != 0xFFFF) {
-            u32 q = sb + my_entry, rank = base_n + sn - n_runs;
-            u64 o = (u64)prefix + base_v + sv - n_vals;
-            bool bad = false;
-            while (q < sub_hi && q < L) {
-                u32 nxt, vals, info;
-                lv_run(w, q - sub_lo, q, L, width, nxt, vals, info);
-                if (vals) {
-                    s_out[rank] = o < n_out ? (u32)o : n_out;
-                    s_info[rank] = info;
-                    rank++;
-                    // Values past NumValues are dropped (fields.go:300,308), but valsFromDefs counts them
-                    // (fields.go:311): a page whose surplus holds max_def is refused instead of counted differently.
-                    if (R.count_level != ERR_POS && o + vals > n_out) {
-                        const u64 t_lo = o > n_out ? o : n_out, t_n = o + vals - t_lo;
-                        if (!(info & 1)) bad = bad || (info >> 1) == R.count_level;
-                        else if (t_n > LV_TAIL_MAX) bad = true;
-                        else {
-                            const u64 cl = (u64)(R.count_level & 0xFF) * 0x0101010101010101ull;
-                            for (u32 i = 0; i < (u32)t_n; i += 16) {
-                                const u32x4 v = run16(rsrc, L, width, (u32)o, info, (u32)t_lo + i);
-                                const u32 nb = (u32)t_n - i < 16 ? (u32)t_n - i : 16;  // bytes of v that are surplus values
-                                const u64 k_lo = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1;
-                                const u64 k_hi = nb >= 16 ? ~0ull : nb > 8 ? (1ull << (8 * (nb - 8))) - 1 : 0;
-                                const u64 x_lo = (v.x | ((u64)v.y << 32)) ^ cl, x_hi = (v.z | ((u64)v.w << 32)) ^ cl;
-                                bad = bad || (lv_zero_bytes(x_lo) & k_lo) || (lv_zero_bytes(x_hi) & k_hi);
-                            }
-                        }
+    // Values past NumValues are dropped (fields.go:300,308), but valsFromDefs counts them (fields.go:311): a
+    // page whose surplus holds max_def is refused instead of being counted differently.
+    if (counting && (u64)prefix + tot_v > n_out) {
+        u64 o = (u64)prefix + my_first;
+        bool bad = false;
+        for (u32 i = 0; i < n_runs; i++) {
+            u32 vals, info;
+            slot(i, vals, info);
+            if (o + vals > n_out) {
+                const u64 t_lo = o > n_out ? o : n_out, t_n = o + vals - t_lo;
+                if (!(info & 1)) bad = bad || (info >> 1) == R.count_level;
+                else if (t_n > LV_TAIL_MAX) bad = true;
+                else {
+                    const u64 cl = (u64)(R.count_level & 0xFF) * 0x0101010101010101ull;
+                    const u32 ginfo = ((sub_lo + (info >> 1)) << 1) | 1;
+                    for (u32 k = 0; k < (u32)t_n; k += 16) {
+                        const u32x4 v = run16(rsrc, L, width, (u32)o, ginfo, (u32)t_lo + k);
+                        const u32 nb = (u32)t_n - k < 16 ? (u32)t_n - k : 16;  // bytes of v that are surplus values
+                        const u64 k_lo = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1;
+                        const u64 k_hi = nb >= 16 ? ~0ull : nb > 8 ? (1ull << (8 * (nb - 8))) - 1 : 0;
+                        const u64 x_lo = (v.x | ((u64)v.y << 32)) ^ cl, x_hi = (v.z | ((u64)v.w << 32)) ^ cl;
+                        bad = bad || (lv_zero_bytes(x_lo) & k_lo) || (lv_zero_bytes(x_hi) & k_hi);
                     }
                 }
-                o += vals;
-                q = nxt;
             }
-            if (bad) s_bad = 1;
+            o += vals;
         }
-        if (tid == 0) s_out[m] = o_hi;
+        if (bad) s_bad = 1;
+        __syncthreads();
+        if (tid == 0 && s_bad) set_status(a.status, ST_NONCANONICAL, ot.region);
     }
-    __syncthreads();
-    if (tid == 0 && s_bad) set_status(a.status, ST_NONCANONICAL, ot.region);
-    if (o_hi <= o_lo) return;
 
-    // ---- 7b. expand [o_lo, o_hi): blocks of 16 values at 16-byte aligned addresses of the level array
-    const u32 mis = (u32)((uintptr_t)(R.out + o_lo) & 15);
-    const u32 vbase = o_lo - mis;                 // level index of block 0's first byte (wraps below 0: only differences are used)
-    u8* const dbase = R.out + o_lo - mis;         // its address, 16-byte aligned
-    const u32 v_end = mis + (o_hi - o_lo);
-    const u32 n_blk = (v_end + 15) >> 4;
-    const bool counting = R.count_level != ERR_POS;
+    // ---- 7. expand.  U values of this super-tile are wanted: level indices [prefix, prefix + U).  They are
+    // produced window by window: the runs are first assembled into a dense stream of `width` bits per value in
+    // LDS, every thread putting its own runs in place (a run that is longer than LV_SEG_SERIAL words is written
+    // by its whole wave), then the stream is unpacked to one byte per value, 16 values per thread and step, with
+    // aligned 16-byte stores.  Bit LV_DENSE_BIAS of the stream is the window's first value.
+    const u32 U = prefix >= n_out ? 0 : (tot_v < (u64)(n_out - prefix) ? (u32)tot_v : n_out - prefix);
+    const u32 V = width ? (LV_DENSE_BITS / width) : LV_DENSE_BITS;  // values per window
     const u64 cl64 = (u64)(R.count_level & 0xFF) * 0x0101010101010101ull;
+    const u64 rep_mul = (width & (width - 1)) || !width ? 0 : ~0ull / ((1ull << width) - 1);  // 1 in every width-th bit
     u32 cnt = 0;
-    for (u32 b = tid; b < n_blk; b += LV_THREADS) {
-        const u32 v0 = b * 16;
-        const u32 lo_v = v0 > mis ? v0 : mis, hi_v = v0 + 16 < v_end ? v0 + 16 : v_end;
-        const u32 x0 = vbase + v0, lo = vbase + lo_v, hi = vbase + hi_v;  // level indices
-        // last run that starts at or before lo (run 0 starts at o_lo <= lo)
-        u32 ra = 0, rb = m;
-        while (rb - ra > 1) {
-            const u32 mid = (ra + rb) >> 1;
-            if (s_out[mid] <= lo) ra = mid; else rb = mid;
+    for (u32 W0 = 0; W0 < U; W0 += V) {
+        const u32 W1 = U - W0 < V ? U : W0 + V;
+        const u32 n_words = LV_DENSE_BIAS / 32 + ((W1 - W0) * width + 31) / 32 + 6;  // a few spare words: blocks read past the end
+        for (u32 i = tid; i < n_words; i += LV_THREADS) dense[i] = 0;
+        __syncthreads();
+        // ---- 7a. assemble
+        if (width) {
+            u64 ra = my_first;
+            for (u32 i = 0; i < LV_SLOTS; i++) {  // the same trip count for every lane of a wave: long runs need all of them
+                const bool have = i < n_runs;
+                if (!__any(have)) break;
+                u32 vals = 0, info = 0;
+                if (have) slot(i, vals, info);
+                const u64 rb = ra + vals;
+                const bool on = have && ra < W1 && rb > W0;
+                u32 b0 = 0, b1 = 0, pay = 0, r0 = 0;
+                u64 pat = 0, sbit0 = 0;
+                bool bp = false, live = false;
+                if (on) {
+                    const u32 s = ra > W0 ? (u32)ra : W0, t = rb < W1 ? (u32)rb : W1;
+                    b0 = LV_DENSE_BIAS + (s - W0) * width;
+                    b1 = LV_DENSE_BIAS + (t - W0) * width;
+                    bp = info & 1;
+                    if (bp) {
+                        pay = sub_lo + (info >> 1);
+                        sbit0 = (u64)(s - ra) * width;
+                        live = true;
+                    } else {
+                        const u32 v = info >> 1;
+                        live = v != 0;  // zeros are there already
+                        if (rep_mul) pat = v * rep_mul;
+                        else { pat = v; for (u32 sft = width; sft < 64; sft <<= 1) pat |= pat << sft; }
+                        if (s == W0 && t == W1) s_fill = v + 1;  // the whole window is this run: stage 7b skips the stream
+                        if (width & (width - 1)) r0 = (((b0 >> 5) - LV_DENSE_BIAS / 32) * 32) % width;
+                    }
+                }
+                const u32 j0 = b0 >> 5, j1 = live ? (b1 - 1) >> 5 : 0;
+                // word j of the segment: its bits, masked to [b0, b1)
+                auto word_bits = [&](u32 jw, u32 bb0, u32 bb1, bool is_bp, u64 pt, u32 rr, u32 py, u64 sb0) -> u32 {
+                    u32 x;
+                    if (is_bp) {
+                        // source bit that lands on bit 0 of word jw; packed bytes past the block end read as 0 (rle.go:203-213)
+                        const int64_t S = (int64_t)sb0 + (int64_t)(jw * 32) - (int64_t)bb0;
+                        const u64 sbit = S >= 0 ? (u64)S : sb0;
+                        const u64 byte = (u64)py + (sbit >> 3);
+                        if (byte + 8 <= (u64)se + 8) {  // inside the LDS image (py >= sb)
+                            const u32 rb_ = (u32)byte - sb, sh = (rb_ & 3) * 8 + ((u32)sbit & 7);
+                            x = __builtin_amdgcn_alignbit(img[(rb_ >> 2) + 1], img[rb_ >> 2], sh);
+                        } else x = (u32)(load_u64_guarded(rsrc, byte < 0xFFFFFFFFull ? (u32)byte : 0xFFFFFFFFu, L) >> (sbit & 7));
+                        if (S < 0) x <<= (u32)(-S);
+                    } else x = (u32)(pt >> rr);
+                    u32 m = 0xFFFFFFFFu;
+                    if (jw == bb0 >> 5) m &= 0xFFFFFFFFu << (bb0 & 31);
+                    if (jw == (bb1 - 1) >> 5) m &= 0xFFFFFFFFu >> (31 - ((bb1 - 1) & 31));
+                    return x & m;
+                };
+                const bool is_long = live && j1 - j0 >= LV_SEG_SERIAL;
+                if (live && !is_long) {
+                    u32 rr = r0;
+                    for (u32 jw = j0; jw <= j1; jw++) {
+                        const u32 x = word_bits(jw, b0, b1, bp, pat, rr, pay, sbit0);
+                        if (x) atomicOr(&dense[jw], x);
+                        if (width & (width - 1)) { rr += 32 % width; if (rr >= width) rr -= width; }
+                    }
+                }
+                u64 lm = __ballot(is_long);
+                while (lm) {
+                    const int l = __ffsll((unsigned long long)lm) - 1;
+                    lm &= lm - 1;
+                    const u32 c_b0 = __shfl(b0, l), c_b1 = __shfl(b1, l), c_pay = __shfl(pay, l);
+                    const u64 c_sb = __shfl(sbit0, l);
+                    const bool c_bp = __shfl((u32)bp, l) != 0;
+                    const u64 c_pat = __shfl(pat, l);
+                    const u32 c_j0 = c_b0 >> 5, c_j1 = (c_b1 - 1) >> 5;
+                    for (u32 jw = c_j0 + lane; jw <= c_j1; jw += 64) {
+                        u32 rr = 0;
+                        if (width & (width - 1)) rr = ((jw - LV_DENSE_BIAS / 32) * 32) % width;
+                        const u32 x = word_bits(jw, c_b0, c_b1, c_bp, c_pat, rr, c_pay, c_sb);
+                        if (x) atomicOr(&dense[jw], x);
+                    }
+                }
+                ra = rb;
+            }
         }
-        u64 acc_lo = 0, acc_hi = 0;
-        u32 r = ra;
-        do {
-            const u32 so = s_out[r], sn_ = s_out[r + 1];
-            const u32 start = so > lo ? so : lo;
-            if (sn_ > start) merge16(acc_lo, acc_hi, run16(rsrc, L, width, so, s_info[r], start), start - x0);
-            r++;
-        } while (r < m && s_out[r] < hi);
-        u8* const dst = dbase + v0;
-        if (hi_v - lo_v == 16) {
+        __syncthreads();
+        LV_STAMP(12);
+        // ---- 7b. unpack [W0, W1) to level indices [g_lo, g_hi): blocks of 16 values at 16-byte aligned addresses
+        const u32 g_lo = prefix + W0, g_hi = prefix + W1;
+        const u32 fill = s_fill;
+        const u32 mis = (u32)((uintptr_t)(R.out + g_lo) & 15);
+        u8* const dbase = R.out + g_lo - mis;
+        const u32 v_end = mis + (g_hi - g_lo);
+        const u32 n_blk = (v_end + 15) >> 4;
+        for (u32 b = tid; b < n_blk; b += LV_THREADS) {
+            const u32 v0 = b * 16;
+            const u32 lo_v = v0 > mis ? v0 : mis, hi_v = v0 + 16 < v_end ? v0 + 16 : v_end;
             u32x4 v;
-            v.x = (u32)acc_lo; v.y = (u32)(acc_lo >> 32); v.z = (u32)acc_hi; v.w = (u32)(acc_hi >> 32);
-            *(u32x4*)dst = v;
-        } else {
-            for (u32 k = lo_v - v0; k < hi_v - v0; k++) dst[k] = (u8)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8)));
+            if (fill) {
+                const u32 f4 = (fill - 1) * 0x01010101u;
+                v = u32x4{f4, f4, f4, f4};
+            } else v = lv_dense16(dense, (u32)((int)LV_DENSE_BIAS + ((int)v0 - (int)mis) * (int)width), width);
+            u8* const dst = dbase + v0;
+            const u64 acc_lo = v.x | ((u64)v.y << 32), acc_hi = v.z | ((u64)v.w << 32);
+            if (hi_v - lo_v == 16) *(u32x4*)dst = v;
+            else for (u32 k = lo_v - v0; k < hi_v - v0; k++) dst[k] = (u8)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8)));
+            if (counting) {
+                const u32 k0 = lo_v - v0, k1 = hi_v - v0;  // bytes [k0, k1) of the block are mine
+                auto keep = [](u32 a0, u32 a1) -> u64 {     // 0xFF in bytes [a0, a1) of a 64-bit word, 0 <= a0 <= a1 <= 8
+                    const u64 hi_m = a1 >= 8 ? ~0ull : (1ull << (8 * a1)) - 1;
+                    const u64 lo_m = a0 >= 8 ? ~0ull : (1ull << (8 * a0)) - 1;
+                    return hi_m & ~lo_m;
+                };
+                const u64 keep_lo = keep(k0 < 8 ? k0 : 8, k1 < 8 ? k1 : 8);
+                const u64 keep_hi = keep(k0 > 8 ? k0 - 8 : 0, k1 > 8 ? k1 - 8 : 0);
+                cnt += __popcll(lv_zero_bytes(acc_lo ^ cl64) & keep_lo) + __popcll(lv_zero_bytes(acc_hi ^ cl64) & keep_hi);
+            }
         }
-        if (counting) {
-            const u32 k0 = lo_v - v0, k1 = hi_v - v0;  // bytes [k0, k1) of the block are mine
-            auto keep = [](u32 a0, u32 a1) -> u64 {     // 0xFF in bytes [a0, a1) of a 64-bit word, 0 <= a0 <= a1 <= 8
-                const u64 hi_m = a1 >= 8 ? ~0ull : (1ull << (8 * a1)) - 1;
-                const u64 lo_m = a0 >= 8 ? ~0ull : (1ull << (8 * a0)) - 1;
-                return hi_m & ~lo_m;
-            };
-            const u64 keep_lo = keep(k0 < 8 ? k0 : 8, k1 < 8 ? k1 : 8);
-            const u64 keep_hi = keep(k0 > 8 ? k0 - 8 : 0, k1 > 8 ? k1 - 8 : 0);
-            cnt += __popcll(lv_zero_bytes(acc_lo ^ cl64) & keep_lo) + __popcll(lv_zero_bytes(acc_hi ^ cl64) & keep_hi);
+        if (W1 < U) {
+            __syncthreads();  // the stream is rewritten
+            if (tid == 0) s_fill = 0;
         }
     }
+    LV_STAMP(13);
     if (counting) {
         for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
         if (lane == 0) s_wc[wv] = cnt;
