@@ -319,7 +319,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         auto want = [&](int which, size_t bytes) { cap[which] = bytes; o[which] = ap.take(bytes + 64); };
         if (C.max_def > 0) {
             want(PQD_OUT_DEFS, C.n_levels);
-            want(PQD_OUT_VALIDITY, (C.n_levels + 7) / 8);
+            cap[PQD_OUT_VALIDITY] = (C.n_levels + 7) / 8;  // placed in the range that is zeroed before every run (below)
         }
         if (C.max_rep > 0) {
             want(PQD_OUT_REPS, C.n_levels);
@@ -395,9 +395,9 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                 push_prefix(pl->btile_prefix, ((u64)P.num_values + BT - 1) / BT, ovf);
             }
         }
-        if (C.max_def > 0) {
+        if (C.max_rep > 0) {  // per-row offsets: repeated columns only (otherwise row r is level r)
             pl->row_chunks.push_back((u32)c);
-            push_prefix(pl->rtile_prefix, (C.n_levels + RT - 1) / RT, ovf);  // validity words come from these tiles too
+            push_prefix(pl->rtile_prefix, (C.n_levels + RT - 1) / RT, ovf);
         }
     }
     if (ovf) return fail(ctx, PQD_E_UNSUPPORTED, "batch too large for 32-bit tile indices");
@@ -450,6 +450,9 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     // reset to 0 every run
     const size_t o_zero = ap.total;
     const size_t o_pdyn = ap.take(n_pages * sizeof(PageDyn));
+    // validity bitmaps: the level kernel ORs the words that two workgroups share
+    for (size_t c = 0; c < n_chunks; c++)
+        if (pl->chunks[c].max_def > 0) off_out[c * 9 + PQD_OUT_VALIDITY] = ap.take(pl->outs[c].cap[PQD_OUT_VALIDITY] + 64);
     const size_t o_status = ap.take(16);
     const size_t o_lvticket = ap.take(16);
     const size_t o_lvpos = ap.take((size_t)pl->n_lvtiles * 8), o_lvval = ap.take((size_t)pl->n_lvtiles * 8);  // hand-off granules
@@ -482,6 +485,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         const ChunkRec& C = pl->chunks[pl->pages[R.page].chunk];
         const u64 lo = (u64)(uintptr_t)R.out;
         R.out = (R.count_level == ERR_POS ? C.reps : C.defs) + lo;
+        R.run_base = lo;                                            // level index of the page's first level in its chunk
+        R.out2 = R.count_level == ERR_POS ? nullptr : C.validity;   // definition levels also yield the validity bitmap
     }
     for (Region& R : pl->sregions) {
         R.out = pl->chunks[pl->pages[R.page].chunk].offsets;

@@ -61,10 +61,10 @@ struct Region {
     u32 width;       // level bit width
     u32 tile_base;   // first tile of the region in the global tile numbering
     u32 otile_base;  // first expand tile (levels)
-    u64 run_base;    // first entry of the region in the run table (levels)
+    u64 run_base;    // first entry of the region in the run table (levels); page path: level index of the page's first level in its chunk
     u64 n_out;       // levels: values to emit (page num_values); strings: upper bound of values in the page
     u8* out;         // levels: destination of value 0; strings: the chunk's offsets array
-    u8* out2;        // strings: the chunk's chars array
+    u8* out2;        // strings: the chunk's chars array; page path, definition levels: the chunk's validity bitmap (zeroed before the run)
     u32 page;        // page index
     u32 count_level; // levels: count values equal to this into page_dyn[page].nn; ERR_POS = do not count
     u32 group_base;  // first hop group of the region in the global group numbering

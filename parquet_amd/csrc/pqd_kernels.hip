@@ -1614,6 +1614,7 @@ __global__ __launch_bounds__(64) void k_page_scan(const ChunkRec* __restrict__ c
         if (C.max_def == 0 && C.width_bytes) run_vals = C.req_values;
         chunk_dyn[c].n_values = run_vals;
         chunk_dyn[c].chars = run_chars;
+        if (C.max_def > 0 && C.max_rep == 0) chunk_dyn[c].n_rows = C.n_levels;  // not repeated: every level is a row
         if (C.phys_type == PT_BYTE_ARRAY) {
             if (run_chars > 0x7fffffffull) set_status(status, ST_UNSUPPORTED, c);
             else ((int32_t*)C.offsets)[run_vals] = (int32_t)run_chars;
@@ -1986,7 +1987,6 @@ __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunk
     const u32 rt = blockIdx.x;
     const u32 k = find_owner(rtile_prefix, n_rchunks, rt);
     const ChunkRec C = chunks[chunk_ids[k]];
-    if (WRITE && C.max_rep == 0) return;  // rows == levels: no offsets are materialised
     const u64 n = C.n_levels;
     const u64 i0 = (u64)(rt - rtile_prefix[k]) * RT + threadIdx.x * 16;
     u32 valid = 0, starts = 0;
@@ -1995,10 +1995,6 @@ __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunk
         valid = eq_mask16(load16_guarded(C.defs, i0, n), (u32)C.max_def) & in_range;
         starts = C.max_rep > 0 ? eq_mask16(load16_guarded(C.reps, i0, n), 0) & in_range : in_range;
         if (i0 == 0) starts |= 1;  // the first level opens a row whatever its rep level (write_repeated.go:62-80)
-    }
-    if (!WRITE) {
-        // validity bitmap: 16 bits per thread
-        if (i0 < n) ((unsigned short*)C.validity)[i0 >> 4] = (unsigned short)valid;
     }
     // block-wide exclusive scan of (row starts, valid)
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2052,10 +2048,6 @@ __global__ __launch_bounds__(1024) void k_rows_scan(const ChunkRec* __restrict__
     if (k >= n_rchunks) return;
     const u32 c = chunk_ids[k];
     const ChunkRec C = chunks[c];
-    if (C.max_rep == 0) {  // not repeated: every level is a row
-        if (threadIdx.x == 0) chunk_dyn[c].n_rows = C.n_levels;
-        return;
-    }
     // every thread owns a contiguous slice of the chunk's tiles: slice sums, block scan, slice bases
     const u32 t0 = rtile_prefix[k], t1 = rtile_prefix[k + 1];
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

@@ -139,6 +139,8 @@ static __device__ __forceinline__ u32x4 lv_dense16(const u32* dn, u32 bit, u32 w
     }
 }
 
+// bit i of the result = bit 8 i + 7 of x
+static __device__ __forceinline__ u32 lv_msb_gather(u64 x) { return (u32)(((x >> 7) * 0x0102040810204080ull) >> 56); }
 // 0x80 in every byte of x that is zero
 static __device__ __forceinline__ u64 lv_zero_bytes(u64 x) {
     return ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) & 0x8080808080808080ull;
@@ -448,6 +450,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     const u32 U = prefix >= n_out ? 0 : (tot_v < (u64)(n_out - prefix) ? (u32)tot_v : n_out - prefix);
     const u32 V = width ? (LV_DENSE_BITS / width) : LV_DENSE_BITS;  // values per window
     const u64 cl64 = (u64)(R.count_level & 0xFF) * 0x0101010101010101ull;
+    u8* const vbits = counting ? R.out2 : nullptr;  // validity bitmap of the chunk, bit i = level i of the chunk
     const u64 rep_mul = (width & (width - 1)) || !width ? 0 : ~0ull / ((1ull << width) - 1);  // 1 in every width-th bit
     u32 cnt = 0;
     for (u32 W0 = 0; W0 < U; W0 += V) {
@@ -556,15 +559,16 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
             if (hi_v - lo_v == 16) *(u32x4*)dst = v;
             else for (u32 k = lo_v - v0; k < hi_v - v0; k++) dst[k] = (u8)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8)));
             if (counting) {
-                const u32 k0 = lo_v - v0, k1 = hi_v - v0;  // bytes [k0, k1) of the block are mine
-                auto keep = [](u32 a0, u32 a1) -> u64 {     // 0xFF in bytes [a0, a1) of a 64-bit word, 0 <= a0 <= a1 <= 8
-                    const u64 hi_m = a1 >= 8 ? ~0ull : (1ull << (8 * a1)) - 1;
-                    const u64 lo_m = a0 >= 8 ? ~0ull : (1ull << (8 * a0)) - 1;
-                    return hi_m & ~lo_m;
-                };
-                const u64 keep_lo = keep(k0 < 8 ? k0 : 8, k1 < 8 ? k1 : 8);
-                const u64 keep_hi = keep(k0 > 8 ? k0 - 8 : 0, k1 > 8 ? k1 - 8 : 0);
-                cnt += __popcll(lv_zero_bytes(acc_lo ^ cl64) & keep_lo) + __popcll(lv_zero_bytes(acc_hi ^ cl64) & keep_hi);
+                // bit k: value k of the block equals max_def (fields.go:220-228); bits [k0, k1) are mine
+                const u32 k0 = lo_v - v0, k1 = hi_v - v0;
+                const u32 eq = lv_msb_gather(lv_zero_bytes(acc_lo ^ cl64)) | (lv_msb_gather(lv_zero_bytes(acc_hi ^ cl64)) << 8);
+                const u32 mine = eq & ((0xFFFFu >> (16 - k1)) & (0xFFFFu << k0));
+                cnt += __popc(mine);
+                if (vbits) {
+                    const u64 li = R.run_base + g_lo + v0 - mis;  // chunk level index of the block's first value: a multiple of 16
+                    if (k1 - k0 == 16) ((unsigned short*)vbits)[li >> 4] = (unsigned short)mine;
+                    else if (mine) atomicOr((u32*)vbits + (li >> 5), mine << (li & 16));  // a block shared with another workgroup or page
+                }
             }
         }
         if (W1 < U) {
