@@ -7,7 +7,8 @@
 // The position of a run header is only known after every header before it has been parsed.  A super-tile is
 // LV_T bytes of one level block and belongs to one workgroup of LV_THREADS threads, 16 bytes per thread:
 //   1. sweep       every byte is a possible header.  A thread sweeps its 16 bytes backwards and memoises, per
-//                  start, where the chain that starts there leaves the 16 bytes (positions only, 16 bits each).
+//                  start, where the chain that starts there leaves the 16 bytes and how many values it passes
+//                  (16 bits each).
 //   2. groups      the same per 256-byte group (16 sub-tiles), one round per sub-tile from the last to the first.
 //   3. exits       for the first LV_TC starts of the super-tile: where the chain leaves the super-tile.
 //   4. hand-off    the true chain enters where the super-tile before it says (one 8-byte granule per boundary,
@@ -16,10 +17,13 @@
 //                  hand-off and one LDS lookup; everything below happens after the successor has been served.
 //   5. resolve     one lane hops from group to group, one lane per group hops through its sub-tiles: every
 //                  thread learns where the true chain enters its 16 bytes.
-//   6. values      every thread walks its true runs and adds up their values; a workgroup scan and a second
-//                  granule chain (values up to the end of each super-tile) turn that into output offsets.
-//   7. expand      the true runs go to a list in LDS and the workgroup writes its part of the level array, 16
-//                  values per thread and step (aligned 16-byte stores), counting def == max_def on the way.
+//   6. values      the memo of a thread's true entry says how many values its runs hold; a workgroup scan and a
+//                  second granule chain (values up to the end of each super-tile) turn that into output offsets.
+//   7. expand      window by window (65536 bits of output): every thread parses its true runs and puts their
+//                  bits into a dense stream of `width` bits per value in LDS (short runs through a register
+//                  accumulator, long ones word by word, very long ones with the whole wave); the stream is then
+//                  unpacked to one byte per value, 16 values per thread and step, with aligned 16-byte stores,
+//                  counting def == max_def and writing the validity bitmap on the way.
 // A start whose exit does not fit the 16-bit tables (a run that ends more than 64 KB behind the super-tile) is
 // marked FAR; only the true chain ever resolves such a step, by parsing that header again with full arithmetic.
 //
@@ -33,14 +37,14 @@
 
 namespace pqd {
 
-constexpr u32 LV_PITCH = LV_THREADS + 2;        // entries per memo row (row k = starts at offset k of every sub-tile)
+constexpr u32 LV_PITCH = LV_THREADS + 1;        // entries per memo row (row k = starts at offset k of every sub-tile)
 constexpr u32 LV_MEMO = LV_SUB * LV_PITCH;      // entries per memo table
 constexpr u32 LV_FAR = 0xFFFE, LV_ERR = 0xFFFF; // 16-bit exit codes: not representable / the chain fails here
+constexpr u32 LV_VSAT = 0xFFFF;                 // 16-bit value count: this many or more, or unknown
 constexpr u32 LV_GROUP = 256;                   // bytes per hop group
 constexpr u32 LV_GSUB = LV_GROUP / LV_SUB;      // sub-tiles per group
 constexpr u32 LV_NGROUPS = LV_T / LV_GROUP;
 constexpr u32 LV_TC = 512;                      // tabulated entries of a super-tile: its first LV_TC bytes
-constexpr u32 LV_SLOTS = LV_SUB / 2;            // runs with values that can start in one sub-tile: each takes at least 2 bytes (width >= 1)
 constexpr u32 LV_DENSE_BITS = 65536;            // bits of the dense level stream per expand window
 constexpr u32 LV_DENSE_BIAS = 128;              // the stream starts at this bit: a block may begin up to 15 values before the window
 constexpr u32 LV_DENSE_WORDS = LV_DENSE_BIAS / 32 + LV_DENSE_BITS / 32 + 6;
@@ -50,8 +54,7 @@ constexpr u32 LV_TAIL_MAX = 4096;               // bit-packed values past NumVal
 static_assert(LV_SUB == 16, "window loads, memo index and group rounds assume 16-byte sub-tiles");
 static_assert(LV_GSUB * 4 == 64, "one wave = four groups in the group rounds");
 static_assert(LV_TC <= LV_THREADS, "one thread per tabulated entry");
-static_assert(2 * LV_MEMO * 2 >= LV_SLOTS * LV_THREADS * 4 + ((LV_DENSE_WORDS + 3) & ~3u) * 4 + LV_T + 8,
-              "run slots, the dense stream and the byte image reuse the memo tables");
+static_assert(LV_MEMO * 4 >= ((LV_DENSE_WORDS + 3) & ~3u) * 4 + LV_T + 8, "the dense stream and the byte image reuse the sweep memo");
 
 static __device__ __forceinline__ u32 lv_idx(u32 rel) { return (rel & (LV_SUB - 1)) * LV_PITCH + (rel >> 4); }
 
@@ -60,47 +63,60 @@ static __device__ __forceinline__ u32 lv_win32(const u32 (&w)[6], int k) {
     const int d = k >> 2, sh = (k & 3) * 8;
     return sh ? (w[d] >> sh) | (w[d + 1] << (32 - sh)) : w[d];
 }
-// The sweep's step: where the run whose header starts at p ends, for headers of at most 4 bytes (runs of fewer
-// than 2^27 values or groups): the same answer as rle_step_w32, with LV_NEEDS_PRECISE for a longer header.
-constexpr u32 LV_NEEDS_PRECISE = 0xFFFFFFFEu;
-static __device__ __forceinline__ u32 lv_next_fast(u32 lo, u32 p, u32 L, u32 w) {
-    const u32 s = ~lo & 0x80808080u;                                  // the stop bits
-    const u32 n = ((u32)__builtin_ctz(s | 0x80000000u) >> 3) + 1;     // header bytes
-    const u32 a = lo & (s ^ (s - 1));                                 // the header's bytes
-    const u32 h = (a & 0x7F) | ((a >> 1) & 0x3F80) | ((a >> 2) & 0x1FC000) | ((a >> 3) & 0xFE00000);
-    const u32 q = p + n, cnt = h >> 1, bw = (w + 7) >> 3;
-    const bool bp = (h & 1) != 0;
-    const u32 prod = w * cnt;                                         // < 2^30
-    const u32 bp_nxt = prod >= L - q ? L : q + prod;
-    bool bad = n > L - p;                                             // header cut off by the block end
-    bad = bad | (bp ? ((w != 0) & (q >= L)) : (bw > L - q));          // io.EOF on the packed bytes / on the value
-    return s == 0 ? LV_NEEDS_PRECISE : bad ? ERR_POS : bp ? bp_nxt : q + bw;
-}
-
-// bytes k..k+7 and byte k+8 of the window for a run-time k in [0, 16)
-static __device__ __forceinline__ void lv_win_dyn(const u32 (&w)[6], u32 k, u32& lo, u32& hi, u32& b8) {
-    const u32 d = k >> 2, sh = (k & 3) * 8;
-    const u32 a = d == 0 ? w[0] : d == 1 ? w[1] : d == 2 ? w[2] : w[3];
-    const u32 b = d == 0 ? w[1] : d == 1 ? w[2] : d == 2 ? w[3] : w[4];
-    const u32 c = d == 0 ? w[2] : d == 1 ? w[3] : d == 2 ? w[4] : w[5];
+// bytes r..r+7 and byte r+8 of the super-tile's LDS image (r < LV_T).  The runs of the true chain are parsed from
+// there: picking registers of the thread's window by a run-time index would put the window into scratch memory.
+static __device__ __forceinline__ void lv_win_img(const u32* img, u32 r, u32& lo, u32& hi, u32& b8) {
+    const u32 d = r >> 2, sh = (r & 3) * 8;
+    const u32 a = img[d], b = img[d + 1], c = img[d + 2];
     lo = __builtin_amdgcn_alignbit(b, a, sh);
     hi = __builtin_amdgcn_alignbit(c, b, sh);
     b8 = (c >> sh) & 0xFF;
 }
 
-// One run of the true chain at position q, parsed from the thread's window (k = q - sub_lo): next header,
-// values, and the record the expand step reads: an RLE run carries its value (width <= 8), a bit-packed run
-// the position of its packed bytes.
-static __device__ __forceinline__ void lv_run(const u32 (&w)[6], u32 k, u32 q, u32 L, u32 width, u32& nxt, u32& vals, u32& info) {
-    u32 lo, hi, b8;
-    lv_win_dyn(w, k, lo, hi, b8);
-    rle_step_w32(lo, hi, q, L, width, nxt, vals, info);
-    if (!(info & 1)) {
-        const u32 d = (info >> 1) - q;  // the value byte sits 1..8 bytes after q
-        u32 val = 0;
-        if (width > 0 && nxt != ERR_POS) val = d < 4 ? (lo >> (8 * d)) & 0xFF : d < 8 ? (hi >> (8 * (d - 4))) & 0xFF : b8;
-        info = val << 1;
-    } else if (width == 0) info = 0;  // width 0 bit-packed groups are runs of zeros
+// A run header of at most 4 bytes (fewer than 2^27 values or groups) at position p, from the 4 bytes at p: the
+// same answers as rle_step_w32.  n = header bytes (0: the header is longer, nothing else is valid), nxt = next
+// header or ERR_POS, vals = values of the run, bp = bit-packed.
+static __device__ __forceinline__ void lv_header4(u32 lo, u32 p, u32 L, u32 w, u32& n, u32& nxt, u32& vals, bool& bp) {
+    const u32 s = ~lo & 0x80808080u;                                  // the stop bits
+    const u32 nb = ((u32)__builtin_ctz(s | 0x80000000u) >> 3) + 1;    // header bytes
+    const u32 a = lo & (s ^ (s - 1));                                 // the header's bytes
+    const u32 h = (a & 0x7F) | ((a >> 1) & 0x3F80) | ((a >> 2) & 0x1FC000) | ((a >> 3) & 0xFE00000);
+    const u32 q = p + nb, cnt = h >> 1, bw = (w + 7) >> 3;
+    bp = (h & 1) != 0;
+    const u32 prod = w * cnt;                                         // < 2^30
+    const u32 bp_nxt = prod >= L - q ? L : q + prod;
+    bool bad = nb > L - p;                                            // header cut off by the block end
+    bad = bad | (bp ? ((w != 0) & (q >= L)) : (bw > L - q));          // io.EOF on the packed bytes / on the value
+    n = s ? nb : 0;
+    nxt = bad ? ERR_POS : bp ? bp_nxt : q + bw;
+    vals = bad ? 0 : bp ? cnt * 8 : cnt;
+}
+
+// One run of the true chain at position q, parsed from the image (r = q - start of the super-tile): next header, values,
+// and how to produce them: info = value << 1 for an RLE run (width <= 8), position of the packed bytes << 1 | 1
+// for a bit-packed run, whose first 32 packed bits are pay32 when pay_ok.
+static __device__ __forceinline__ void lv_run(const u32* img, u32 r, u32 q, u32 L, u32 width, u32& nxt, u32& vals, u32& info,
+                                              u32& pay32, bool& pay_ok) {
+    u32 lo, hi, b8, n;
+    bool bp;
+    lv_win_img(img, r, lo, hi, b8);
+    lv_header4(lo, q, L, width, n, nxt, vals, bp);
+    if (n) {
+        const u32 after = (u32)((lo | ((u64)hi << 32)) >> (8 * n));  // the 4 bytes behind the header
+        pay32 = after;
+        pay_ok = true;
+        info = bp ? (width ? ((q + n) << 1) | 1u : 0u) : (width ? (after & 0xFF) << 1 : 0u);  // width 0: runs of zeros
+    } else {
+        rle_step_w32(lo, hi, q, L, width, nxt, vals, info);
+        pay32 = 0;
+        pay_ok = false;
+        if (!(info & 1)) {
+            const u32 d = (info >> 1) - q;  // the value byte sits 5..8 bytes after q
+            u32 val = 0;
+            if (width > 0 && nxt != ERR_POS) val = d < 4 ? (lo >> (8 * d)) & 0xFF : d < 8 ? (hi >> (8 * (d - 4))) & 0xFF : b8;
+            info = val << 1;
+        } else if (width == 0) info = 0;
+    }
 }
 
 // 16 consecutive values (one per result byte) of the dense stream dn (W bits per value), starting at bit `bit`
@@ -139,6 +155,30 @@ static __device__ __forceinline__ u32x4 lv_dense16(const u32* dn, u32 bit, u32 w
     }
 }
 
+// Word jw of the dense stream for the part [bb0, bb1) (stream bits) of a run: an RLE run repeats its value
+// (pt = the value in every `width` bits, rr = phase of the word's first bit inside a value), a bit-packed run
+// copies its packed bytes (stream bit bb0 = packed bit sb0 of the bytes at py), from the LDS image of the
+// super-tile where they lie inside it, else from memory; packed bytes past the block end read as 0
+// (rle.go:203-213).
+static __device__ __forceinline__ u32 lv_word_bits(u32 jw, u32 bb0, u32 bb1, bool is_bp, u64 pt, u32 rr, u32 py, u64 sb0,
+                                                   const u8* rsrc, u32 L, const u32* img, u32 sb, u32 se) {
+    u32 x;
+    if (is_bp) {
+        const int64_t S = (int64_t)sb0 + (int64_t)(jw * 32) - (int64_t)bb0;  // packed bit that lands on bit 0 of word jw
+        const u64 sbit = S >= 0 ? (u64)S : sb0;
+        const u64 byte = (u64)py + (sbit >> 3);
+        if (byte <= (u64)se) {  // inside the image (py >= sb): two of its words hold the 39 bits needed
+            const u32 rb = (u32)byte - sb, sh = (rb & 3) * 8 + ((u32)sbit & 7);
+            x = __builtin_amdgcn_alignbit(img[(rb >> 2) + 1], img[rb >> 2], sh);
+        } else x = (u32)(load_u64_guarded(rsrc, byte < 0xFFFFFFFFull ? (u32)byte : 0xFFFFFFFFu, L) >> (sbit & 7));
+        if (S < 0) x <<= (u32)(-S);
+    } else x = (u32)(pt >> rr);
+    u32 m = 0xFFFFFFFFu;
+    if (jw == bb0 >> 5) m &= 0xFFFFFFFFu << (bb0 & 31);
+    if (jw == (bb1 - 1) >> 5) m &= 0xFFFFFFFFu >> (31 - ((bb1 - 1) & 31));
+    return x & m;
+}
+
 // bit i of the result = bit 8 i + 7 of x
 static __device__ __forceinline__ u32 lv_msb_gather(u64 x) { return (u32)(((x >> 7) * 0x0102040810204080ull) >> 56); }
 // 0x80 in every byte of x that is zero
@@ -161,13 +201,15 @@ static __device__ __forceinline__ void lv_publish(u64* g, u32 v) {
 #define LV_STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(u64)ticket * LV_STAMPS + (i)] = wall_clock64(); } while (0)
 
 __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ src_base, const LvArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short s_memo[2 * LV_MEMO];  // sweep memo | group memo; later the run list
+    // sweep memo: exit | values << 16 per start; later the dense stream and the byte image of the super-tile
+    __shared__ __attribute__((aligned(16))) u32 s_memo[LV_MEMO];
+    __shared__ unsigned short s_la[LV_MEMO];  // group memo: exit per start
     __shared__ unsigned short s_tc[LV_TC], s_entry[LV_THREADS], s_gentry[LV_NGROUPS];
     __shared__ u32 s_wc[LV_WAVES];
     __shared__ u64 s_wv[LV_WAVES];
     __shared__ u32 s_ticket, s_e, s_ex, s_prefix, s_bad, s_fill;
-    unsigned short* const memo0 = s_memo;
-    unsigned short* const la = s_memo + LV_MEMO;
+    u32* const memo0 = s_memo;
+    unsigned short* const la = s_la;
 
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_ticket = atomicAdd(a.ticket, 1u);
@@ -207,20 +249,26 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     }
 
     LV_STAMP(1);
-    // ---- 1. sweep: where the chain of every start leaves my 16 bytes
+    // ---- 1. sweep: where the chain of every start leaves my 16 bytes, and the values it passes on the way
 #pragma unroll
     for (int k = (int)LV_SUB - 1; k >= 0; k--) {
         const u32 p = sub_lo + k;
-        const u32 nxt = lv_next_fast(lv_win32(w, k), p, L, width);
+        u32 n, nxt, vals;
+        bool bp;
+        lv_header4(lv_win32(w, k), p, L, width, n, nxt, vals, bp);
         const bool valid = p < L;
-        const bool in = valid & (nxt < sub_hi) & (nxt < L);  // lands on a later start of mine: its answer is final
+        const bool in = valid & (n != 0) & (nxt < sub_hi) & (nxt < L);  // lands on a later start of mine: its answer is final
         const u32 mi = (u32)k * LV_PITCH + tid;
         const u32 mj = in ? (nxt - sub_lo) * LV_PITCH + tid : mi;
         const u32 t2 = memo0[mj];
         const u32 d = nxt - sb;
-        u32 enc = nxt == ERR_POS ? LV_ERR : d >= LV_FAR ? LV_FAR : d;  // LV_NEEDS_PRECISE is far away too
+        u32 enc = nxt == ERR_POS ? LV_ERR : d >= LV_FAR ? LV_FAR : d;
+        if (n == 0) enc = LV_FAR;  // a longer header: parsed with full arithmetic if the true chain comes here
         if (!valid) enc = LV_ERR;
-        memo0[mi] = (unsigned short)(in ? t2 : enc);
+        u32 v = enc >= LV_FAR ? LV_VSAT : vals;
+        if (in) v += t2 >> 16;
+        v = v < LV_VSAT ? v : LV_VSAT;
+        memo0[mi] = (in ? t2 & 0xFFFF : enc) | (v << 16);
     }
     LV_STAMP(2);
     // ---- 2. groups: a wave owns 1 KiB = 4 groups; round s settles the starts of sub-tile s of every group
@@ -231,7 +279,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
         const u32 g = lane >> 4, k = lane & 15;
         const u32 rel = wv * 1024 + g * LV_GROUP + (u32)s * LV_SUB + k;
         const u32 gend = wv * 1024 + (g + 1) * LV_GROUP;
-        const u32 x = memo0[lv_idx(rel)];
+        const u32 x = memo0[lv_idx(rel)] & 0xFFFF;
         const bool hop = (x < gend) & (x < Lr);
         const u32 y = la[lv_idx(hop ? x : rel)];
         la[lv_idx(rel)] = (unsigned short)(hop ? y : x);
@@ -257,7 +305,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     };
     // the true chain is at p (sb <= p < min(se, L)): where it leaves p's sub-tile / p's group
     auto hop_sub = [&](u32 p) -> u32 {
-        const u32 x = memo0[lv_idx(p - sb)];
+        const u32 x = memo0[lv_idx(p - sb)] & 0xFFFF;
         if (x < LV_FAR) return sb + x;
         if (x == LV_ERR) return ERR_POS;
         const u32 send = (p | (LV_SUB - 1)) + 1;  // sb is a multiple of LV_SUB
@@ -332,31 +380,24 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     __syncthreads();
 
     LV_STAMP(8);
-    // ---- 6. values: every thread parses the true runs that start in its 16 bytes once and keeps those that
-    // hold values in slots of its own (the memo tables are dead: their last readers ran before the barrier
-    // above).  A slot is 32 bits: values (0xFFFF: 65535 or more, parsed again where needed) | how to produce them:
-    //   RLE         (value << 1 | header offset in the sub-tile << 9) << 16
-    //   bit-packed  (1 | offset of the packed bytes from the sub-tile start << 1 | header offset << 6) << 16
-    // The super-tile's bytes go to LDS as well: the packed bytes are read from there when the stream is assembled.
-    u32* const sl = (u32*)s_memo;                               // [LV_SLOTS][LV_THREADS]
-    u32* const dense = sl + LV_SLOTS * LV_THREADS;              // LV_DENSE_WORDS
+    // ---- 6. values of the true runs that start in my 16 bytes: the memo of my entry knows them, unless they
+    // are 65535 or more or a header needs full arithmetic; then the runs are parsed for it
+    const u32 my_entry = active ? s_entry[tid] : 0xFFFF;
+    u64 n_vals = my_entry != 0xFFFF ? memo0[lv_idx(my_entry)] >> 16 : 0;
+    __syncthreads();  // the sweep memo is dead from here on
+    // the super-tile's bytes go to LDS: the true runs are parsed from there
+    u32* const dense = s_memo;                                  // LV_DENSE_WORDS
     u32* const img = dense + ((LV_DENSE_WORDS + 3) & ~3u);      // LV_T / 4 + 2 words: the super-tile and 8 bytes behind it
     *(u32x4*)(img + tid * 4) = u32x4{w[0], w[1], w[2], w[3]};
     if (tid == LV_THREADS - 1) { img[LV_T / 4] = w[4]; img[LV_T / 4 + 1] = w[5]; }
-    const u32 my_entry = active ? s_entry[tid] : 0xFFFF;
-    u32 n_runs = 0;
-    u64 n_vals = 0;
-    if (my_entry != 0xFFFF) {
+    __syncthreads();
+    if (n_vals == LV_VSAT) {
+        n_vals = 0;
         u32 q = sb + my_entry;
         while (q < sub_hi && q < L) {
-            u32 nxt, vals, info;
-            lv_run(w, q - sub_lo, q, L, width, nxt, vals, info);
-            if (vals && width && n_runs < LV_SLOTS) {  // a run with values is at least 2 bytes: never more than LV_SLOTS
-                const u32 qo = q - sub_lo;
-                const u32 how = (info & 1) ? (1u | (((info >> 1) - sub_lo) << 1) | (qo << 6)) : (info | (qo << 9));
-                sl[n_runs * LV_THREADS + tid] = (vals < 0xFFFFu ? vals : 0xFFFFu) | (how << 16);
-                n_runs++;
-            }
+            u32 nxt, vals, info, pay32;
+            bool pay_ok;
+            lv_run(img, q - sb, q, L, width, nxt, vals, info, pay32, pay_ok);
             n_vals += vals;
             q = nxt;  // never ERR_POS: the exit of the super-tile is known to be good
         }
@@ -374,17 +415,6 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
         if (q < wv) base_v += s_wv[q];
         tot_v += s_wv[q];
     }
-    // slot i of this thread: the run's values and (RLE) value << 1 or (bit-packed) offset of the packed bytes << 1 | 1
-    auto slot = [&](u32 i, u32& vals, u32& info) {
-        const u32 x = sl[i * LV_THREADS + tid], how = x >> 16;
-        vals = x & 0xFFFF;
-        info = (how & 1) ? (how & 0x3F) : (how & 0x1FF);
-        if (vals == 0xFFFF) {  // a long run: its count comes from the header once more
-            const u32 qo = (how & 1) ? (how >> 6) & 15 : (how >> 9) & 15;
-            u32 nxt, inf;
-            lv_run(w, qo, sub_lo + qo, L, width, nxt, vals, inf);
-        }
-    };
     LV_STAMP(9);
     if (tid == 0) {
         u32 prefix = 0;
@@ -413,29 +443,33 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     // Values past NumValues are dropped (fields.go:300,308), but valsFromDefs counts them (fields.go:311): a
     // page whose surplus holds max_def is refused instead of being counted differently.
     if (counting && (u64)prefix + tot_v > n_out) {
-        u64 o = (u64)prefix + my_first;
         bool bad = false;
-        for (u32 i = 0; i < n_runs; i++) {
-            u32 vals, info;
-            slot(i, vals, info);
-            if (o + vals > n_out) {
-                const u64 t_lo = o > n_out ? o : n_out, t_n = o + vals - t_lo;
-                if (!(info & 1)) bad = bad || (info >> 1) == R.count_level;
-                else if (t_n > LV_TAIL_MAX) bad = true;
-                else {
-                    const u64 cl = (u64)(R.count_level & 0xFF) * 0x0101010101010101ull;
-                    const u32 ginfo = ((sub_lo + (info >> 1)) << 1) | 1;
-                    for (u32 k = 0; k < (u32)t_n; k += 16) {
-                        const u32x4 v = run16(rsrc, L, width, (u32)o, ginfo, (u32)t_lo + k);
-                        const u32 nb = (u32)t_n - k < 16 ? (u32)t_n - k : 16;  // bytes of v that are surplus values
-                        const u64 k_lo = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1;
-                        const u64 k_hi = nb >= 16 ? ~0ull : nb > 8 ? (1ull << (8 * (nb - 8))) - 1 : 0;
-                        const u64 x_lo = (v.x | ((u64)v.y << 32)) ^ cl, x_hi = (v.z | ((u64)v.w << 32)) ^ cl;
-                        bad = bad || (lv_zero_bytes(x_lo) & k_lo) || (lv_zero_bytes(x_hi) & k_hi);
+        if (my_entry != 0xFFFF) {
+            u64 o = (u64)prefix + my_first;
+            u32 q = sb + my_entry;
+            while (q < sub_hi && q < L) {
+                u32 nxt, vals, info, pay32;
+                bool pay_ok;
+                lv_run(img, q - sb, q, L, width, nxt, vals, info, pay32, pay_ok);
+                if (vals && width && o + vals > n_out) {
+                    const u64 t_lo = o > n_out ? o : n_out, t_n = o + vals - t_lo;
+                    if (!(info & 1)) bad = bad || (info >> 1) == R.count_level;
+                    else if (t_n > LV_TAIL_MAX) bad = true;
+                    else {
+                        const u64 cl = (u64)(R.count_level & 0xFF) * 0x0101010101010101ull;
+                        for (u32 k = 0; k < (u32)t_n; k += 16) {
+                            const u32x4 v = run16(rsrc, L, width, (u32)o, info, (u32)t_lo + k);
+                            const u32 nb = (u32)t_n - k < 16 ? (u32)t_n - k : 16;  // bytes of v that are surplus values
+                            const u64 k_lo = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1;
+                            const u64 k_hi = nb >= 16 ? ~0ull : nb > 8 ? (1ull << (8 * (nb - 8))) - 1 : 0;
+                            const u64 x_lo = (v.x | ((u64)v.y << 32)) ^ cl, x_hi = (v.z | ((u64)v.w << 32)) ^ cl;
+                            bad = bad || (lv_zero_bytes(x_lo) & k_lo) || (lv_zero_bytes(x_hi) & k_hi);
+                        }
                     }
                 }
+                o += vals;
+                q = nxt;
             }
-            o += vals;
         }
         if (bad) s_bad = 1;
         __syncthreads();
@@ -444,98 +478,126 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
 
     // ---- 7. expand.  U values of this super-tile are wanted: level indices [prefix, prefix + U).  They are
     // produced window by window: the runs are first assembled into a dense stream of `width` bits per value in
-    // LDS, every thread putting its own runs in place (a run that is longer than LV_SEG_SERIAL words is written
-    // by its whole wave), then the stream is unpacked to one byte per value, 16 values per thread and step, with
-    // aligned 16-byte stores.  Bit LV_DENSE_BIAS of the stream is the window's first value.
+    // LDS, then the stream is unpacked to one byte per value.  Bit LV_DENSE_BIAS of the stream is the window's
+    // first value.
     const u32 U = prefix >= n_out ? 0 : (tot_v < (u64)(n_out - prefix) ? (u32)tot_v : n_out - prefix);
     const u32 V = width ? (LV_DENSE_BITS / width) : LV_DENSE_BITS;  // values per window
     const u64 cl64 = (u64)(R.count_level & 0xFF) * 0x0101010101010101ull;
     u8* const vbits = counting ? R.out2 : nullptr;  // validity bitmap of the chunk, bit i = level i of the chunk
     const u64 rep_mul = (width & (width - 1)) || !width ? 0 : ~0ull / ((1ull << width) - 1);  // 1 in every width-th bit
+    const bool odd_w = (width & (width - 1)) != 0;
     u32 cnt = 0;
     for (u32 W0 = 0; W0 < U; W0 += V) {
         const u32 W1 = U - W0 < V ? U : W0 + V;
         const u32 n_words = LV_DENSE_BIAS / 32 + ((W1 - W0) * width + 31) / 32 + 6;  // a few spare words: blocks read past the end
         for (u32 i = tid; i < n_words; i += LV_THREADS) dense[i] = 0;
         __syncthreads();
-        // ---- 7a. assemble
+        // ---- 7a. assemble: every thread parses its runs; the loop has the same trip count for all lanes of a
+        // wave because a very long run is written by all of them
         if (width) {
+            u32 q = my_entry != 0xFFFF ? sb + my_entry : ERR_POS;
             u64 ra = my_first;
-            for (u32 i = 0; i < LV_SLOTS; i++) {  // the same trip count for every lane of a wave: long runs need all of them
-                const bool have = i < n_runs;
-                if (!__any(have)) break;
-                u32 vals = 0, info = 0;
-                if (have) slot(i, vals, info);
-                const u64 rb = ra + vals;
-                const bool on = have && ra < W1 && rb > W0;
-                u32 b0 = 0, b1 = 0, pay = 0, r0 = 0;
+            // consecutive short runs collect in a register: bits [0, accn) of acc belong at word accw of the stream
+            u64 acc = 0;
+            u32 accn = 0, accw = 0;
+            auto acc_flush = [&]() {
+                if ((u32)acc) atomicOr(&dense[accw], (u32)acc);
+                if (accn > 32 && (u32)(acc >> 32)) atomicOr(&dense[accw + 1], (u32)(acc >> 32));
+                acc = 0;
+                accn = 0;
+            };
+            for (;;) {
+                const bool act = q < sub_hi && q < L;
+                if (!__any(act)) break;
+                u32 b0 = 0, b1 = 0, pay = 0, nxt = ERR_POS, vals = 0;
                 u64 pat = 0, sbit0 = 0;
-                bool bp = false, live = false;
-                if (on) {
-                    const u32 s = ra > W0 ? (u32)ra : W0, t = rb < W1 ? (u32)rb : W1;
-                    b0 = LV_DENSE_BIAS + (s - W0) * width;
-                    b1 = LV_DENSE_BIAS + (t - W0) * width;
-                    bp = info & 1;
-                    if (bp) {
-                        pay = sub_lo + (info >> 1);
-                        sbit0 = (u64)(s - ra) * width;
-                        live = true;
-                    } else {
-                        const u32 v = info >> 1;
-                        live = v != 0;  // zeros are there already
-                        if (rep_mul) pat = v * rep_mul;
-                        else { pat = v; for (u32 sft = width; sft < 64; sft <<= 1) pat |= pat << sft; }
-                        if (s == W0 && t == W1) s_fill = v + 1;  // the whole window is this run: stage 7b skips the stream
-                        if (width & (width - 1)) r0 = (((b0 >> 5) - LV_DENSE_BIAS / 32) * 32) % width;
+                bool bp = false, is_long = false;
+                if (act) {
+                    u32 info, pay32;
+                    bool pay_ok;
+                    lv_run(img, q - sb, q, L, width, nxt, vals, info, pay32, pay_ok);
+                    const u64 rb = ra + vals;
+                    if (vals && ra < W1 && rb > W0) {
+                        const u32 s = ra > W0 ? (u32)ra : W0, t = rb < W1 ? (u32)rb : W1;
+                        b0 = LV_DENSE_BIAS + (s - W0) * width;
+                        b1 = LV_DENSE_BIAS + (t - W0) * width;
+                        const u32 nbits = b1 - b0;
+                        bp = info & 1;
+                        bool live = true;
+                        if (!bp) {
+                            const u32 v = info >> 1;
+                            if (rep_mul) pat = v * rep_mul;
+                            else { pat = v; for (u32 sft = width; sft < 64; sft <<= 1) pat |= pat << sft; }
+                            if (s == W0 && t == W1) s_fill = v + 1;  // the whole window is this run: stage 7b skips the stream
+                            live = v != 0;  // zeros are there already
+                        } else {
+                            pay = info >> 1;
+                            sbit0 = (u64)(s - ra) * width;
+                        }
+                        is_long = live && (((b0 & 31) + nbits + 31) >> 5) > LV_SEG_SERIAL;
+                        if (live && !is_long) {
+                            // the run's bits join the accumulator, at most 32 at a time
+                            if (accn == 0 || accw * 32 + accn != b0) {
+                                acc_flush();
+                                accw = b0 >> 5;
+                                accn = b0 & 31;
+                            }
+                            auto append = [&](u32 bits, u32 n) {
+                                acc |= (u64)bits << accn;
+                                accn += n;
+                                if (accn >= 32) {
+                                    if ((u32)acc) atomicOr(&dense[accw], (u32)acc);
+                                    acc >>= 32;
+                                    accw++;
+                                    accn -= 32;
+                                }
+                            };
+                            if (!bp) {
+                                u32 ph = 0;
+                                for (u32 rem = nbits; rem;) {
+                                    const u32 take = rem < 32 ? rem : 32;
+                                    append((u32)(pat >> ph) & (0xFFFFFFFFu >> (32 - take)), take);
+                                    rem -= take;
+                                    if (odd_w) { ph += 32 % width; if (ph >= width) ph -= width; }
+                                }
+                            } else if (nbits <= 32 && pay_ok && s == ra) {
+                                append(pay32 & (0xFFFFFFFFu >> (32 - nbits)), nbits);  // the packed bits are in my registers
+                            } else {
+                                u64 sbit = sbit0;
+                                for (u32 rem = nbits; rem;) {
+                                    const u32 take = rem < 32 ? rem : 32;
+                                    const u64 byte = (u64)pay + (sbit >> 3);
+                                    u32 x;
+                                    if (byte <= (u64)se) {  // inside the image: two of its words hold the 39 bits needed
+                                        const u32 rbt = (u32)byte - sb, sh = (rbt & 3) * 8 + ((u32)sbit & 7);
+                                        x = __builtin_amdgcn_alignbit(img[(rbt >> 2) + 1], img[rbt >> 2], sh);
+                                    } else x = (u32)(load_u64_guarded(rsrc, byte < 0xFFFFFFFFull ? (u32)byte : 0xFFFFFFFFu, L) >> (sbit & 7));
+                                    append(x & (0xFFFFFFFFu >> (32 - take)), take);
+                                    sbit += take;
+                                    rem -= take;
+                                }
+                            }
+                        }
                     }
-                }
-                const u32 j0 = b0 >> 5, j1 = live ? (b1 - 1) >> 5 : 0;
-                // word j of the segment: its bits, masked to [b0, b1)
-                auto word_bits = [&](u32 jw, u32 bb0, u32 bb1, bool is_bp, u64 pt, u32 rr, u32 py, u64 sb0) -> u32 {
-                    u32 x;
-                    if (is_bp) {
-                        // source bit that lands on bit 0 of word jw; packed bytes past the block end read as 0 (rle.go:203-213)
-                        const int64_t S = (int64_t)sb0 + (int64_t)(jw * 32) - (int64_t)bb0;
-                        const u64 sbit = S >= 0 ? (u64)S : sb0;
-                        const u64 byte = (u64)py + (sbit >> 3);
-                        if (byte + 8 <= (u64)se + 8) {  // inside the LDS image (py >= sb)
-                            const u32 rb_ = (u32)byte - sb, sh = (rb_ & 3) * 8 + ((u32)sbit & 7);
-                            x = __builtin_amdgcn_alignbit(img[(rb_ >> 2) + 1], img[rb_ >> 2], sh);
-                        } else x = (u32)(load_u64_guarded(rsrc, byte < 0xFFFFFFFFull ? (u32)byte : 0xFFFFFFFFu, L) >> (sbit & 7));
-                        if (S < 0) x <<= (u32)(-S);
-                    } else x = (u32)(pt >> rr);
-                    u32 m = 0xFFFFFFFFu;
-                    if (jw == bb0 >> 5) m &= 0xFFFFFFFFu << (bb0 & 31);
-                    if (jw == (bb1 - 1) >> 5) m &= 0xFFFFFFFFu >> (31 - ((bb1 - 1) & 31));
-                    return x & m;
-                };
-                const bool is_long = live && j1 - j0 >= LV_SEG_SERIAL;
-                if (live && !is_long) {
-                    u32 rr = r0;
-                    for (u32 jw = j0; jw <= j1; jw++) {
-                        const u32 x = word_bits(jw, b0, b1, bp, pat, rr, pay, sbit0);
-                        if (x) atomicOr(&dense[jw], x);
-                        if (width & (width - 1)) { rr += 32 % width; if (rr >= width) rr -= width; }
-                    }
+                    ra = rb;
                 }
                 u64 lm = __ballot(is_long);
                 while (lm) {
                     const int l = __ffsll((unsigned long long)lm) - 1;
                     lm &= lm - 1;
                     const u32 c_b0 = __shfl(b0, l), c_b1 = __shfl(b1, l), c_pay = __shfl(pay, l);
-                    const u64 c_sb = __shfl(sbit0, l);
+                    const u64 c_sb = __shfl(sbit0, l), c_pat = __shfl(pat, l);
                     const bool c_bp = __shfl((u32)bp, l) != 0;
-                    const u64 c_pat = __shfl(pat, l);
                     const u32 c_j0 = c_b0 >> 5, c_j1 = (c_b1 - 1) >> 5;
                     for (u32 jw = c_j0 + lane; jw <= c_j1; jw += 64) {
-                        u32 rr = 0;
-                        if (width & (width - 1)) rr = ((jw - LV_DENSE_BIAS / 32) * 32) % width;
-                        const u32 x = word_bits(jw, c_b0, c_b1, c_bp, c_pat, rr, c_pay, c_sb);
+                        const u32 rr = odd_w ? ((jw - LV_DENSE_BIAS / 32) * 32) % width : 0;
+                        const u32 x = lv_word_bits(jw, c_b0, c_b1, c_bp, c_pat, rr, c_pay, c_sb, rsrc, L, img, sb, se);
                         if (x) atomicOr(&dense[jw], x);
                     }
                 }
-                ra = rb;
+                if (act) q = nxt;
             }
+            acc_flush();
         }
         __syncthreads();
         LV_STAMP(12);

@@ -17,7 +17,7 @@ from parquet_amd import _native as N  # noqa: E402
 from parquet_amd import reader as R  # noqa: E402
 
 NAMES = ["start", "loaded", "sweep", "groups", "exits", "entry known", "published", "group walk", "sub walk",
-         "values", "prefix known", "surplus chk", "assembled", "expanded"]
+         "values", "prefix known", "surplus chk", "assembled(last win)", "expanded"]
 
 
 def main():
