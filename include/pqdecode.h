@@ -165,6 +165,25 @@ int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
 int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block, size_t block_len,
                    int out_elem_size, void* out_host, size_t max_values, int64_t* n_decoded);
 
+/* ---- the same decode for callers that cannot allocate -----------------------------------------
+ * No counterpart in the reference.  It is for callers that must not call hipMalloc: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid allocation.  This entry point allocates nothing (no
+ * hipMalloc / hipFree, no host allocation) and does not synchronise: it queues three kernels on the context's
+ * stream and returns.  Inputs and outputs are the caller's DEVICE buffers:
+ *   runs_device    the hybrid runs of one level block WITHOUT the 4-byte length in front; 8 readable bytes of
+ *                  slack behind runs_len are not required
+ *   out_device     uint8[max_values]; width 0..8
+ *   result_device  int64[2]: {values the block holds (saturated at 2^32 - 1; min(that, max_values) were
+ *                  written), 0 or a negative pqd_status}
+ * The tables of the decode live in a static device array of the library (about 50 KB per GPU, held until the
+ * process ends), which limits a block to PQD_NOALLOC_MAX_BLOCK_BYTES of runs; larger blocks are refused with
+ * PQD_E_ARG.  Every call on one GPU shares that array: calls that overlap on one GPU (two contexts, two
+ * streams) race; calls on one context are ordered by its stream.  Read the results with pqd_copy_to_host,
+ * which waits for the stream. */
+#define PQD_NOALLOC_MAX_BLOCK_BYTES (16u << 20)
+int pqd_rle_decode_noalloc(pqd_ctx* ctx, int width, const void* runs_device, size_t runs_len,
+                           void* out_device, size_t max_values, int64_t* result_device);
+
 /* ---- standalone level ENCODE: rle.(*RLE).Write + Bytes (internal/rle/rle.go:48-156) for one block ----
  * The mirror of pqd_rle_decode and the first piece of the write path: `levels` (one byte each, host memory)
  * become int32 LE length + hybrid runs, byte for byte what the reference encoder writes: at a group

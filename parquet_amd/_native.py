@@ -87,6 +87,7 @@ DECODE_SYMBOLS = {
     "pqd_decode": (C.c_int, [_P, C.POINTER(ChunkDesc), C.c_size_t, C.POINTER(PageDesc), C.c_size_t,
                              _P, C.c_size_t, C.POINTER(_P)]),
     "pqd_rle_decode": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int, _P, C.c_size_t, C.POINTER(C.c_int64)]),
+    "pqd_rle_decode_noalloc": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "pqd_rle_encode": (C.c_int, [_P, C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_int64)]),
     "pqd_encode_pages": (C.c_int, [_P, C.POINTER(EncPage), C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(EncResult), C.POINTER(C.c_int64)]),
     "pqd_snappy_sizes": (C.c_int, [_P, C.c_size_t, C.POINTER(SnappyBlock), C.c_size_t]),

@@ -142,6 +142,13 @@ int pqd_create(int device, pqd_ctx** out) {
         delete ctx;
         return PQD_E_HIP;
     }
+    // device address of the static scratch of pqd_rle_decode_noalloc, looked up once per device
+    if (lv_scratch_init(device) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream2);
+        delete ctx;
+        return PQD_E_HIP;
+    }
     const char* g = getenv("PQD_COPY_GRID");
     if (g && atoi(g) > 0) ctx->copy_grid = (u32)atoi(g);
     const char* ov = getenv("PQD_OVERLAP");
@@ -848,6 +855,29 @@ int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block_, size_t block_len
     if (len < 0 || (size_t)len > block_len - 4) return fail(ctx, PQD_E_CORRUPT, "level block length outside the buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    if (esz == 1) {
+        // one byte per value: the single-pass level kernel of the page path, its tables in a scratch buffer
+        ArenaPlan ap1;
+        const size_t o_src = ap1.take((size_t)len + 64), o_out = ap1.take(max_values + 64);
+        const size_t o_sc = ap1.take(lv_scratch_bytes((size_t)len)), o_res = ap1.take(16);
+        u8* A1 = nullptr;
+        hipError_t e1 = hipMalloc((void**)&A1, ap1.total);
+        if (e1 != hipSuccess) return fail(ctx, PQD_E_NOMEM, "hipMalloc failed", e1);
+        struct Free1 { u8* p; ~Free1() { (void)hipFree(p); } } fr1{A1};
+        if (len) HIP_TRY(ctx, hipMemcpyAsync(A1 + o_src, block + 4, (size_t)len, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, launch_rle_decode_u8(st, A1 + o_sc, width, A1 + o_src, (u32)len, A1 + o_out, (u32)max_values, (long long*)(A1 + o_res)));
+        long long res[2] = {0, 0};
+        HIP_TRY(ctx, hipMemcpyAsync(res, A1 + o_res, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (res[1]) return fail(ctx, (int)res[1], "malformed level block");
+        *n_decoded = (int64_t)res[0];
+        const u64 n_emit1 = (u64)res[0] < max_values ? (u64)res[0] : max_values;
+        if (n_emit1 == 0) return PQD_OK;
+        if (!out_host) return PQD_E_ARG;
+        HIP_TRY(ctx, hipMemcpyAsync(out_host, A1 + o_out, n_emit1, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        return PQD_OK;
+    }
     const u32 n_tiles = ((u32)len + CH_T - 1) / CH_T;
     const u32 n_otiles = (u32)((max_values + OT - 1) / OT);
     const u32 n_groups = (n_tiles + CH_G_LEVELS - 1) / CH_G_LEVELS;
@@ -907,6 +937,20 @@ int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block_, size_t block_len
                                       (u32*)(A + o_otf), (RegionTotal*)(A + o_tot), nullptr, (PageDyn*)(A + o_pdyn)));
     HIP_TRY(ctx, hipMemcpyAsync(out_host, A + o_out, n_emit * (size_t)esz, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    return PQD_OK;
+}
+
+int pqd_rle_decode_noalloc(pqd_ctx* ctx, int width, const void* runs_device, size_t runs_len, void* out_device,
+                           size_t max_values, int64_t* result_device) {
+    if (!ctx || !result_device || (!runs_device && runs_len) || (!out_device && max_values)) return PQD_E_ARG;
+    if (width < 0 || width > 8) return fail(ctx, PQD_E_ARG, "width must be 0..8 (one byte per value)");
+    if (runs_len > PQD_NOALLOC_MAX_BLOCK) return fail(ctx, PQD_E_ARG, "level block larger than PQD_NOALLOC_MAX_BLOCK (16 MiB)");
+    if (max_values > 0x7fffffffu) return fail(ctx, PQD_E_ARG, "max_values too large");
+    void* sc = lv_scratch_ptr(ctx->device);
+    if (!sc) return fail(ctx, PQD_E_HIP, "static scratch not initialised on this device");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_rle_decode_u8(ctx->stream, sc, width, (const u8*)runs_device, (u32)runs_len, (u8*)out_device, (u32)max_values,
+                                      (long long*)result_device));
     return PQD_OK;
 }
 

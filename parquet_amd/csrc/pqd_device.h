@@ -163,6 +163,14 @@ struct LvArgs {
 };
 constexpr u32 LV_STAMPS = 16;
 hipError_t launch_levels(hipStream_t st, const u8* src, const LvArgs& a);
+constexpr u32 LV_ALLOW_SHORT = 1;  // Region.otile_base flag on this path: a block with fewer values than n_out is no error
+// one block on its own (widths 0..8, one byte per value); see pqd_levels.hip
+constexpr size_t PQD_NOALLOC_MAX_BLOCK = 16u << 20;  // bytes of runs the entry point without allocations accepts
+hipError_t lv_scratch_init(int device);
+void* lv_scratch_ptr(int device);
+size_t lv_scratch_bytes(size_t runs_len);
+hipError_t launch_rle_decode_u8(hipStream_t st, void* scratch, int width, const u8* runs, u32 len, u8* out, u32 max_values,
+                                long long* result_device);
 
 hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks, const PageRec* pages, u32 n_pages,
                             PageDyn* page_dyn, ChunkDyn* chunk_dyn, int* status);

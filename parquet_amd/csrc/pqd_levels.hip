@@ -428,7 +428,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
         const u64 incl = (u64)prefix + tot_v;
         lv_publish(a.val_g + R.lv_base + j, incl < 0xFFFFFFFFull ? (u32)incl : 0xFFFFFFFFu);
         if (timeout) set_status(a.status, ST_INTERNAL, ot.region);
-        else if (last && incl < n_out) set_status(a.status, ST_CORRUPT, ot.region);  // defs[:NumValues] out of range
+        else if (last && incl < n_out && !(R.otile_base & LV_ALLOW_SHORT)) set_status(a.status, ST_CORRUPT, ot.region);  // defs[:NumValues] out of range
         s_prefix = prefix;
         s_bad = 0;
         s_fill = 0;
@@ -655,6 +655,92 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
 hipError_t launch_levels(hipStream_t st, const u8* src, const LvArgs& a) {
     if (a.n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_levels, dim3(a.n_tiles), dim3(LV_THREADS), 0, st, src, a);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// One level block decoded on its own (rle.Read, internal/rle/rle.go:159-195, widths 0..8, one byte per value):
+// k_levels over a single region whose tables live in a scratch buffer:
+//   [LvsHead][order: n_tiles LvTile][pos_g: n_tiles u64][val_g: n_tiles u64]
+// k_lv_setup writes the tables and zeroes the granules, k_lv_finish reports {values the block holds (saturated
+// at 2^32 - 1), status} as two int64.  The scratch buffer is either allocated by the caller (pqd_rle_decode) or
+// the static array below (pqd_rle_decode_noalloc), which every call on a device shares.
+// =====================================================================================
+struct LvsHead {
+    Region region;
+    u32 ticket;
+    u32 pad[5];
+    int status[4];
+};
+static_assert(sizeof(LvsHead) % 16 == 0, "the tables behind the head stay aligned");
+static __host__ __device__ size_t lvs_bytes(u32 n_tiles) { return sizeof(LvsHead) + (size_t)n_tiles * (sizeof(LvTile) + 16); }
+static __host__ __device__ u32 lvs_tiles(size_t len) { return len ? (u32)((len + LV_T - 1) / LV_T) : 1; }
+
+constexpr u32 LVS_MAX_TILES = (u32)(PQD_NOALLOC_MAX_BLOCK / LV_T);
+constexpr size_t LVS_STATIC_BYTES = sizeof(LvsHead) + (size_t)LVS_MAX_TILES * (sizeof(LvTile) + 16);
+// Scratch of the entry point that allocates nothing.  In host code this name is only a handle for
+// hipGetSymbolAddress: the device address is looked up once per device (lv_scratch_init) and used from then on.
+static __device__ __align__(256) unsigned char scratch[LVS_STATIC_BYTES];
+constexpr int LVS_MAX_DEVICES = 64;
+static void* g_scratch_ptr[LVS_MAX_DEVICES];
+
+hipError_t lv_scratch_init(int device) {  // the device is current
+    if (device < 0 || device >= LVS_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    g_scratch_ptr[device] = ptr;
+    return hipSuccess;
+}
+void* lv_scratch_ptr(int device) { return device >= 0 && device < LVS_MAX_DEVICES ? g_scratch_ptr[device] : nullptr; }
+size_t lv_scratch_bytes(size_t runs_len) { return lvs_bytes(lvs_tiles(runs_len)); }
+
+__global__ void k_lv_setup(unsigned char* sc, u32 n_tiles, u32 width, u32 len, u8* out, u32 max_values) {
+    LvsHead* const H = (LvsHead*)sc;
+    LvTile* const order = (LvTile*)(sc + sizeof(LvsHead));
+    u64* const pos_g = (u64*)(order + n_tiles);
+    u64* const val_g = pos_g + n_tiles;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_tiles) {
+        order[i] = LvTile{0, i};
+        pos_g[i] = 0;
+        val_g[i] = 0;
+    }
+    if (i == 0) {
+        Region R;
+        R.src_off = 0; R.len = len; R.width = width; R.tile_base = 0;
+        R.otile_base = LV_ALLOW_SHORT;  // fewer values than max_values is no error here
+        R.run_base = 0; R.n_out = max_values; R.out = out; R.out2 = nullptr; R.page = 0;
+        R.count_level = ERR_POS; R.group_base = 0; R.lv_base = 0;
+        H->region = R;
+        H->ticket = 0;
+        H->status[0] = H->status[1] = H->status[2] = H->status[3] = 0;
+    }
+}
+__global__ void k_lv_finish(const unsigned char* sc, u32 n_tiles, long long* result) {
+    const LvsHead* const H = (const LvsHead*)sc;
+    const u64* const val_g = (const u64*)(sc + sizeof(LvsHead) + (size_t)n_tiles * sizeof(LvTile)) + n_tiles;
+    const int st = H->status[0];
+    result[0] = st ? 0 : (long long)(u32)val_g[n_tiles - 1];
+    result[1] = st == 0 ? 0 : st == ST_CORRUPT ? -6 : st == ST_NONCANONICAL ? -7 : st == ST_INTERNAL ? -2 : -5;  // pqd_status
+}
+
+// Queues the decode of one block on `st`; sc = scratch of at least lv_scratch_bytes(len) bytes, 16-byte aligned.
+hipError_t launch_rle_decode_u8(hipStream_t st, void* sc_, int width, const u8* runs, u32 len, u8* out, u32 max_values,
+                                long long* result_device) {
+    unsigned char* const sc = (unsigned char*)sc_;
+    const u32 n_tiles = lvs_tiles(len);
+    hipLaunchKernelGGL(k_lv_setup, dim3((n_tiles + 255) / 256), dim3(256), 0, st, sc, n_tiles, (u32)width, len, out, max_values);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    LvsHead* const H = (LvsHead*)sc;
+    LvTile* const order = (LvTile*)(sc + sizeof(LvsHead));
+    u64* const pos_g = (u64*)(order + n_tiles);
+    LvArgs a{&H->region, order, n_tiles, pos_g, pos_g + n_tiles, &H->ticket, nullptr, H->status, nullptr};
+    e = launch_levels(st, runs, a);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_lv_finish, dim3(1), dim3(1), 0, st, sc, n_tiles, result_device);
     return hipGetLastError();
 }
 

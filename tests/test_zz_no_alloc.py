@@ -1,0 +1,91 @@
+"""The entry point that allocates nothing (pqd_rle_decode_noalloc) against the existing standalone level decode
+(pqd_rle_decode), through the C ABI: bit-exact outputs, on two calls in a row of which the second is smaller, so
+that whatever the first call left in the static scratch array must not leak into the second."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from parquet_amd import _native as N
+from parquet_amd import reader as R
+from parquet_amd.writer import encode_levels
+
+pytestmark = pytest.mark.gpu
+
+
+def _levels(rng, n, width, p_run):
+    """Mixed runs: long equal stretches (RLE) and noisy ones (bit-packed)."""
+    out = np.zeros(n, np.uint8)
+    i = 0
+    while i < n:
+        k = int(rng.integers(1, 200))
+        if rng.random() < p_run:
+            out[i:i + k] = rng.integers(0, 1 << width)
+        else:
+            out[i:i + k] = rng.integers(0, 1 << width, min(k, n - i))
+        i += k
+    return out
+
+
+def _noalloc(ctx, width, block, max_values):
+    runs = np.frombuffer(block, np.uint8)[4:].copy()
+    d_runs = N.decode.pqd_device_alloc(ctx.handle, max(runs.size, 1))
+    d_out = N.decode.pqd_device_alloc(ctx.handle, max(max_values, 1))
+    d_res = N.decode.pqd_device_alloc(ctx.handle, 16)
+    assert d_runs and d_out and d_res
+    try:
+        if runs.size:
+            assert N.decode.pqd_copy_to_device(ctx.handle, d_runs, runs.ctypes.data, runs.size) == 0
+        poison = np.full(max(max_values, 1), 0xAB, np.uint8)
+        assert N.decode.pqd_copy_to_device(ctx.handle, d_out, poison.ctypes.data, poison.size) == 0
+        rc = N.decode.pqd_rle_decode_noalloc(ctx.handle, width, d_runs, runs.size, d_out, max_values, d_res)
+        assert rc == 0, (rc, N.decode.pqd_last_error(ctx.handle))
+        res = np.zeros(2, np.int64)
+        assert N.decode.pqd_copy_to_host(ctx.handle, res.ctypes.data, d_res, 16) == 0  # waits for the stream
+        out = np.zeros(max(max_values, 1), np.uint8)
+        assert N.decode.pqd_copy_to_host(ctx.handle, out.ctypes.data, d_out, out.size) == 0
+        return out[:max_values], int(res[0]), int(res[1])
+    finally:
+        for p in (d_runs, d_out, d_res):
+            N.decode.pqd_device_free(ctx.handle, p)
+
+
+def _compare(ctx, width, levels, max_values):
+    block = encode_levels(width, levels)
+    want, n_want = R.rle_decode(ctx, width, block, max_values)
+    got, n_got, st = _noalloc(ctx, width, block, max_values)
+    assert st == 0
+    assert n_got == n_want
+    n = min(n_want, max_values)
+    assert np.array_equal(got[:n], want[:n])
+    assert np.array_equal(want[:min(n, levels.size)], levels[:min(n, levels.size)])
+    assert (got[n:] == 0xAB).all()  # nothing written past what the block holds
+
+
+def test_noalloc_matches_rle_decode_two_calls_second_smaller():
+    rng = np.random.default_rng(77)
+    ctx = R.Context(0)
+    try:
+        big = _levels(rng, 1_500_000, 2, 0.5)      # > 20 super-tiles of runs: the hand-off chain is exercised
+        small = _levels(rng, 3_001, 2, 0.5)
+        _compare(ctx, 2, big, big.size)
+        _compare(ctx, 2, small, small.size)        # second call, smaller input, same static scratch
+        _compare(ctx, 1, _levels(rng, 70_000, 1, 0.3), 50_000)  # truncated by max_values
+        _compare(ctx, 4, _levels(rng, 10, 4, 0.0), 64)          # fewer values than max_values
+    finally:
+        ctx.close()
+
+
+def test_noalloc_rejects_oversized_and_reports_corrupt():
+    ctx = R.Context(0)
+    try:
+        d = N.decode.pqd_device_alloc(ctx.handle, 64)
+        assert N.decode.pqd_rle_decode_noalloc(ctx.handle, 1, d, (16 << 20) + 1, d, 1, d) == N.E_ARG
+        assert N.decode.pqd_rle_decode_noalloc(ctx.handle, 9, d, 4, d, 1, d) == N.E_ARG
+        N.decode.pqd_device_free(ctx.handle, d)
+        # a header cut off by the block end: corrupt, reported through result[1]
+        bad = np.array([4, 0, 0, 0, 0x03, 0xFF, 0x80, 0x80], np.uint8).tobytes()
+        _, n, st = _noalloc(ctx, 1, bad, 100)
+        assert st == N.E_CORRUPT and n == 0
+    finally:
+        ctx.close()
