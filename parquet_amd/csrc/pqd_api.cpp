@@ -612,7 +612,7 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     if (n_lreg) HIP_TRY(ctx, launch_levels(st, src, pl->lv));
     HIP_TRY(ctx, launch_page_scan(st, pl->d_chunks, n_chunks, pl->d_pages, n_pages, pl->d_page_dyn, pl->d_chunk_dyn, pl->d_status));
     HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, (u32)pl->bool_pages.size(), pl->n_btiles,
-                              pl->d_chunks, pl->d_page_dyn));
+                              pl->d_chunks, pl->d_page_dyn, pl->d_status));
     if (n_sreg) {
         if (str_early) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join, 0));
         else HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 0));
@@ -780,6 +780,19 @@ int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks, cons
     // page decoder then reads them there like uncompressed pages (pageData, fields.go:358-402).
     std::vector<pqd_chunk_desc> cv(chunks, chunks + n_chunks);
     std::vector<pqd_page_desc> pv(pages, pages + n_pages);
+    // Every page as the caller describes it must lie inside the host buffer.  Below, SNAPPY pages move to an area
+    // behind the file bytes and the plan is made for that larger range, so this is the only place where the
+    // descriptors of the uncompressed chunks are checked against the real length (the planner reads level block
+    // lengths from src_host at these offsets).
+    for (size_t c = 0; c < n_chunks; c++) {
+        if (chunks[c].first_page < 0 || chunks[c].n_pages < 0 || (size_t)chunks[c].first_page + (size_t)chunks[c].n_pages > n_pages)
+            return fail(ctx, PQD_E_ARG, "chunk page range out of bounds");
+        for (int k = 0; k < chunks[c].n_pages; k++) {
+            const pqd_page_desc& pd = pages[(size_t)chunks[c].first_page + k];
+            if (pd.src_off < 0 || pd.payload_len < 0 || (uint64_t)pd.src_off + (uint64_t)pd.payload_len > src_len)
+                return fail(ctx, PQD_E_CORRUPT, "page payload outside the source buffer");
+        }
+    }
     std::vector<pqd_snappy_block> blocks;
     std::vector<size_t> block_page;
     for (size_t c = 0; c < n_chunks; c++) {

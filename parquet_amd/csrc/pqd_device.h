@@ -175,7 +175,7 @@ hipError_t launch_rle_decode_u8(hipStream_t st, void* scratch, int width, const 
 hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks, const PageRec* pages, u32 n_pages,
                             PageDyn* page_dyn, ChunkDyn* chunk_dyn, int* status);
 hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids, const u32* btile_prefix,
-                        u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn);
+                        u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn, const int* status);
 hipError_t launch_str_check(hipStream_t st, const PageRec* pages, const ChunkRec* chunks, const PageDyn* page_dyn,
                             const Region* regions, u32 n_regions, const RegionTotal* totals, int* status);
 hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_prefix, const u32* chunk_ids, u32 n_rchunks,

@@ -778,7 +778,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
                                                          const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
                                                          const TileEntry* __restrict__ tile_entry,
                                                          const u32x4* __restrict__ str_cp,
-                                                         const PageDyn* __restrict__ page_dyn, const u32* __restrict__ tile_region) {
+                                                         const PageDyn* __restrict__ page_dyn, const u32* __restrict__ tile_region,
+                                                         const int* __restrict__ status) {
+    if (status && status[0]) return;  // an earlier kernel found the batch corrupt: value counts and offsets are not to be trusted
     __shared__ __attribute__((aligned(16))) u32 s_buf[STR_MG][STR_LDS_WORDS];
     __shared__ u32 s_bits[STR_MG][64], s_last[STR_MG][2];
     const u32 lane = threadIdx.x, t0 = blockIdx.x * STR_MG;
@@ -1586,6 +1588,10 @@ __global__ __launch_bounds__(64) void k_page_scan(const ChunkRec* __restrict__ c
         if (pi < C.n_pages) {
             const PageRec P = pages[C.first_page + pi];
             nn = C.max_def > 0 ? page_dyn[C.first_page + pi].nn : P.num_values;
+            if (nn > P.num_values) {  // never more values than levels: every offset below depends on it
+                set_status(status, ST_CORRUPT, C.first_page + pi);
+                nn = P.num_values;
+            }
             if (C.phys_type == PT_BYTE_ARRAY) {
                 if (4 * nn > P.val_len) set_status(status, ST_CORRUPT, C.first_page + pi);
                 else chars = P.val_len - 4 * nn;
@@ -1631,7 +1637,8 @@ __global__ __launch_bounds__(64) void k_page_scan(const ChunkRec* __restrict__ c
 __global__ __launch_bounds__(256) void k_bools(const u8* __restrict__ src_base, const PageRec* __restrict__ pages,
                                                const u32* __restrict__ page_ids, const u32* __restrict__ btile_prefix,
                                                u32 n_bpages, const ChunkRec* __restrict__ chunks,
-                                               const PageDyn* __restrict__ page_dyn) {
+                                               const PageDyn* __restrict__ page_dyn, const int* __restrict__ status) {
+    if (status[0]) return;  // an earlier kernel found the batch corrupt: value counts and offsets are not to be trusted
     const u32 bt = blockIdx.x;
     const u32 k = find_owner(btile_prefix, n_bpages, bt);
     const u32 pg = page_ids[k];
@@ -1640,9 +1647,9 @@ __global__ __launch_bounds__(256) void k_bools(const u8* __restrict__ src_base, 
     const PageDyn D = page_dyn[pg];
     const u64 count = C.max_def > 0 ? D.nn : P.num_values;
     const u64 i0 = (u64)(bt - btile_prefix[k]) * BT + threadIdx.x * 16;
-    if (i0 >= count) return;
+    if (i0 >= count || (i0 >> 3) >= P.val_len) return;  // never past the page's values region (k_page_scan reports it)
     const u8* s = src_base + P.val_src_off + (i0 >> 3);
-    const u32 bits = (u32)s[0] | (i0 + 8 < count ? (u32)s[1] << 8 : 0);
+    const u32 bits = (u32)s[0] | (i0 + 8 < count && (i0 >> 3) + 1 < P.val_len ? (u32)s[1] << 8 : 0);
     u8* dst = C.values + D.val_off + i0;
     const u32 n = count - i0 < 16 ? (u32)(count - i0) : 16;
     if (n == 16) {
@@ -2146,7 +2153,7 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
     } else if (a.n_tiles) {
         if constexpr (KIND == KIND_STRINGS)
             hipLaunchKernelGGL(k_str_mark, dim3((a.n_tiles + STR_MG - 1) / STR_MG), dim3(CH_THREADS), 0, st, src, a.regions,
-                               a.tile_prefix, a.n_regions, a.n_tiles, a.tile_entry, (const u32x4*)a.str_cp, page_dyn, a.tile_region);
+                               a.tile_prefix, a.n_regions, a.n_tiles, a.tile_entry, (const u32x4*)a.str_cp, page_dyn, a.tile_region, status);
         else
             hipLaunchKernelGGL((k_chain<KIND, true, CHAIN_NT_MARK>), dim3(a.n_tiles), dim3(CHAIN_NT_MARK), 0, st, src, a.regions, a.tile_prefix,
                                a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn, a.tile_region);
@@ -2192,9 +2199,9 @@ hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks
 }
 
 hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids, const u32* btile_prefix,
-                        u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn) {
+                        u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn, const int* status) {
     if (n_btiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_bools, dim3(n_btiles), dim3(256), 0, st, src, pages, page_ids, btile_prefix, n_bpages, chunks, page_dyn);
+    hipLaunchKernelGGL(k_bools, dim3(n_btiles), dim3(256), 0, st, src, pages, page_ids, btile_prefix, n_bpages, chunks, page_dyn, status);
     LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -663,3 +663,82 @@ def test_graph_replay_mode(monkeypatch):
             plan.close()
     finally:
         c.close()
+
+
+def test_short_def_block_on_multi_page_string_and_bool_columns(ctx):
+    """A definition-level block that decodes cleanly but holds far fewer values than the page's num_values, on
+    pages of more than one expand tile, after an earlier decode has left the device arena full of stale counts:
+    the error comes back as a status and nothing is written through stale counts (the process survives and the
+    next decode is correct)."""
+    rng = np.random.default_rng(5)
+    cols = [Column("s", N.BYTE_ARRAY, [1]), Column("b", N.BOOLEAN, [1])]
+    good = H.build_file(cols, 60000, 60000, 20000, rng, p_null=0.1, str_len=(8, 32))
+    H.check_file(good, ctx)  # dirties the arena
+
+    def short_page(n_claimed, n_real, string):
+        defs = np.ones(n_real, np.uint8)
+        block = encode_levels(1, defs)
+        if string:
+            vals = b"".join((3).to_bytes(4, "little") + b"abc" for _ in range(n_real))
+        else:
+            vals = bytes([0xFF] * ((n_real + 7) // 8))
+        return block + vals, n_claimed
+
+    w = ParquetWriter(cols, stats=False)
+    w.begin_row_group()
+    for string, ci in ((True, 0), (False, 1)):
+        for _ in range(3):
+            payload, n = short_page(3 * 4096 + 17, 100, string)
+            w.write_raw_page(ci, payload, n)
+    w.end_row_group(3 * (3 * 4096 + 17))
+    bad = w.finish()
+    w.close()
+    with pytest.raises(N.PqdError) as e:
+        H.gpu_file(bad, ctx)
+    assert e.value.code == N.E_CORRUPT
+    H.check_file(good, ctx)
+
+
+def test_surplus_levels_equal_to_max_def_are_refused(ctx):
+    """Levels past num_values are dropped from Defs (fields.go:300,308) but counted by valsFromDefs (fields.go:311).
+    A zero surplus (what every encoder pads with) decodes; a surplus that holds max_def would make the reference
+    read values the page does not have: refused as non-canonical."""
+    cols = [Column("a", N.INT32, [1])]
+
+    def one(block_levels, n):
+        w = ParquetWriter(cols, stats=False)
+        w.begin_row_group()
+        nn = int(np.count_nonzero(np.asarray(block_levels[:n]) == 1))
+        w.write_raw_page(0, encode_levels(1, np.asarray(block_levels, np.uint8)) + np.arange(nn, dtype=np.int32).tobytes(), n)
+        w.end_row_group(n)
+        b = w.finish()
+        w.close()
+        return b
+
+    H.check_file(one([1, 0, 1, 1, 0, 0, 0, 0], 5), ctx)                 # bit-packed group, zero surplus
+    H.check_file(one([1] * 20 + [0] * 20, 25), ctx)                     # RLE surplus of zeros
+    for lv, n in (([1, 0, 1, 1, 0, 0, 1, 0], 5), ([0] * 8 + [1] * 30, 10), ([1] * 9000, 4100)):
+        with pytest.raises(N.PqdError) as e:
+            H.gpu_file(one(lv, n), ctx)
+        assert e.value.code == N.E_NONCANONICAL, (lv[:10], n, e.value.code)
+
+
+def test_decode_rejects_uncompressed_page_outside_the_host_buffer_in_a_mixed_codec_batch(ctx):
+    """pqd_decode moves SNAPPY pages behind the file bytes, which makes the device range longer than the host
+    buffer; the descriptors of uncompressed chunks must still be checked against the host length."""
+    rng = np.random.default_rng(9)
+    cols = [Column("a", N.INT32, [1]), Column("b", N.INT32, [1])]
+    buf = H.build_file(cols, 3000, 3000, 1000, rng, p_null=0.2, codec=1)
+    pf = R.ParquetFile(buf)
+    chunks, nc, pages, npg = pf.descriptors(0, 1)
+    cv = (N.ChunkDesc * nc)(*[chunks[i] for i in range(nc)])
+    pv = (N.PageDesc * npg)(*[pages[i] for i in range(npg)])
+    assert cv[0].codec == 1 and cv[1].codec == 1
+    cv[1].codec = 0                                     # pretend chunk 1 is uncompressed ...
+    for k in range(cv[1].first_page, cv[1].first_page + cv[1].n_pages):
+        pv[k].src_off = pf.size + 16                    # ... with pages just past the end of the host buffer
+        pv[k].payload_len = 32
+        pv[k].rep_bytes, pv[k].def_bytes = 0, -1        # level block length to be read from the host copy
+    with pytest.raises(N.PqdError) as e:
+        R.decode_host(ctx, cv, nc, pv, npg, pf.address, pf.size)
+    assert e.value.code == N.E_CORRUPT
