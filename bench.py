@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """Benchmark: device-resident Parquet page decode GB/s on MI355X.
 
-A step = one pass of the decoder over one batch of column chunks that is already resident in HBM:
-configs[1] of BASELINE.json — flat required int32 / int64 / float64 columns, 1M rows per page (pure
-PLAIN decode, bandwidth bound).  GB/s counts algorithmic bytes: page payload bytes read + decoded bytes
-the reference materialises (here 8 B per int32 value, 16 B per int64/float64 value).
+A step = one pass of the decoder over one batch of column chunks that is already resident in HBM.  The
+headline workload is "mixed": this GPU's share of configs[4] of BASELINE.json, i.e. the columns of configs[1]
+(flat required int32 / int64 / float64), configs[2] (optional int32 and string, 10 % nulls) and configs[3]
+(Person{Being, Username, Friends []Being}) side by side, row groups and pages of 1M rows.  GB/s counts
+algorithmic bytes: page payload bytes read + decoded bytes the reference materialises (levels 1 B each, dense
+values, string offsets + chars).  The single-config workloads (flat / optint / optstr / nested) are measured
+in the same run on smaller files and reported under "per_workload".
 
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
@@ -30,14 +33,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pages", type=int, default=None, help="pages per column chunk (default 64 for flat, 8 otherwise)")
-    ap.add_argument("--row-groups", type=int, default=None, help="row groups per GPU (default 4 for flat, 2 otherwise)")
+    ap.add_argument("--pages", type=int, default=None, help="pages per column chunk (default 1 for mixed, 64 for flat, 8 otherwise)")
+    ap.add_argument("--row-groups", type=int, default=None, help="row groups per GPU (default 96 for mixed, 4 for flat, 2 otherwise)")
     ap.add_argument("--rows-per-page", type=int, default=1_000_000)
-    ap.add_argument("--workload", default="flat", choices=["flat", "optional", "optint", "optstr", "nested"])
+    ap.add_argument("--workload", default="mixed", choices=["mixed", "flat", "optional", "optint", "optstr", "nested"])
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-workload lines measured beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="per CPU baseline leg (one thread, all cores)")
     ap.add_argument("--pcie", action="store_true", help="also measure the rate including H2D and D2H copies")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
     ap.add_argument("--force-dist", action="store_true",
@@ -47,130 +51,250 @@ def parse_args():
     return ap.parse_args()
 
 
-def build_flat_file(rg_ids, pages, rows_per_page):
-    """configs[1]: three required columns, `pages` pages of `rows_per_page` rows per chunk."""
-    from parquet_amd import _native as N
-    from parquet_amd.writer import Column, ParquetWriter
-    cols = [Column("i32", N.INT32, [0]), Column("i64", N.INT64, [0]), Column("f64", N.DOUBLE, [0])]
-    w = ParquetWriter(cols, stats=True)
-    w.reserve(len(rg_ids) * pages * rows_per_page * 20 + (1 << 20))
-    for g in rg_ids:
-        rng = np.random.default_rng(1000 + g)
-        w.begin_row_group()
-        for ci, c in enumerate(cols):
-            for _ in range(pages):
-                if c.phys_type == N.INT32:
-                    v = rng.integers(-2**31, 2**31 - 1, rows_per_page, dtype=np.int64).astype(np.int32)
-                elif c.phys_type == N.INT64:
-                    v = rng.integers(-2**63, 2**63 - 1, rows_per_page, dtype=np.int64)
-                else:
-                    v = rng.random(rows_per_page)
-                w.write_page(ci, v)
-        w.end_row_group(pages * rows_per_page)
-    buf = w.finish()
-    w.close()
-    return buf
+class Expect:
+    """What a synthetic file must decode to: totals of every chunk and, for the chunks of the first and the last
+    row group, the arrays themselves (kept from the generator's inputs)."""
+
+    def __init__(self):
+        self.totals = {}   # (rg index in the file, column) -> (n_levels, n_values, char bytes)
+        self.arrays = {}   # (rg index, column) -> dict of arrays, first and last row group only
+        self._cur = {}
+
+    def page(self, rg, col, keep, values, defs=None, reps=None, offsets=None):
+        nl = defs.size if defs is not None else (offsets.size - 1 if offsets is not None else values.size)
+        nv = offsets.size - 1 if offsets is not None else values.size
+        ch = int(offsets[-1]) if offsets is not None else 0
+        t = self.totals.get((rg, col), (0, 0, 0))
+        self.totals[(rg, col)] = (t[0] + nl, t[1] + nv, t[2] + ch)
+        if keep:
+            d = self.arrays.setdefault((rg, col), {"values": [], "defs": [], "reps": [], "lens": []})
+            d["values"].append(np.ascontiguousarray(values).view(np.uint8).copy())
+            if defs is not None:
+                d["defs"].append(defs.copy())
+            if reps is not None:
+                d["reps"].append(reps.copy())
+            if offsets is not None:
+                d["lens"].append(np.diff(offsets).astype(np.int64))
 
 
-def build_optional_file(rg_ids, pages, rows_per_page, which="both"):
-    """configs[2]: optional int32 and string columns, 10 % nulls (def level width 1)."""
-    from parquet_amd import _native as N
-    from parquet_amd.writer import Column, ParquetWriter
-    cols = [Column("oi32", N.INT32, [1]), Column("ostr", N.BYTE_ARRAY, [1])]
-    cols = {"both": cols, "int": cols[:1], "str": cols[1:]}[which]
-    w = ParquetWriter(cols, stats=True)
-    for g in rg_ids:
-        rng = np.random.default_rng(2000 + g)
-        w.begin_row_group()
-        for ci, c in enumerate(cols):
-            for _ in range(pages):
-                mask = rng.random(rows_per_page) >= 0.1
-                nv = int(mask.sum())
-                defs = mask.astype(np.uint8)
-                if c.phys_type == N.INT32:
-                    w.write_page(ci, rng.integers(-2**31, 2**31 - 1, nv, dtype=np.int64).astype(np.int32), defs=defs)
-                else:
-                    lens = rng.integers(8, 33, nv)
-                    offs = np.zeros(nv + 1, np.int32)
-                    np.cumsum(lens, out=offs[1:])
-                    chars = rng.integers(97, 123, int(offs[-1]), dtype=np.uint8)
-                    w.write_page(ci, chars, defs=defs, offsets=offs)
-        w.end_row_group(pages * rows_per_page)
-    buf = w.finish()
-    w.close()
-    return buf
+def _flat_cols(N, Column):
+    return [Column("i32", N.INT32, [0]), Column("i64", N.INT64, [0]), Column("f64", N.DOUBLE, [0])]
 
 
-def build_nested_file(rg_ids, pages, rows_per_page):
-    """configs[3]: Person{Being{id, age*}, username, Friends []Being}: rep/def levels, ragged offsets."""
-    from parquet_amd import _native as N
-    from parquet_amd.writer import Column, ParquetWriter
-    cols = [Column("being.id", N.INT32, [0, 0]), Column("being.age", N.INT32, [0, 1]),
+def _optional_cols(N, Column):
+    return [Column("oi32", N.INT32, [1]), Column("ostr", N.BYTE_ARRAY, [1])]
+
+
+def _person_cols(N, Column):
+    # README.md:146-159 Person{Being{ID int32; Age *int32}; Username string; Friends []Being}
+    return [Column("being.id", N.INT32, [0, 0]), Column("being.age", N.INT32, [0, 1]), Column("username", N.BYTE_ARRAY, [0]),
             Column("friends.id", N.INT32, [2, 0]), Column("friends.age", N.INT32, [2, 1])]
+
+
+def _gen_page(N, name, rng, n):
+    """One page of `n` rows of the named column: (values, defs, reps, offsets)."""
+    if name == "i32" or name == "being.id":
+        return rng.integers(-2**31, 2**31 - 1, n, dtype=np.int64).astype(np.int32), None, None, None
+    if name == "i64":
+        return rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64), None, None, None
+    if name == "f64":
+        return rng.random(n), None, None, None
+    if name == "oi32":
+        mask = rng.random(n) >= 0.1
+        return rng.integers(-2**31, 2**31 - 1, int(mask.sum()), dtype=np.int64).astype(np.int32), mask.astype(np.uint8), None, None
+    if name == "ostr":
+        mask = rng.random(n) >= 0.1
+        nv = int(mask.sum())
+        lens = rng.integers(8, 33, nv)
+        offs = np.zeros(nv + 1, np.int32)
+        np.cumsum(lens, out=offs[1:])
+        return rng.integers(97, 123, int(offs[-1]), dtype=np.uint8), mask.astype(np.uint8), None, offs
+    if name == "username":
+        lens = rng.integers(3, 11, n)
+        offs = np.zeros(n + 1, np.int32)
+        np.cumsum(lens, out=offs[1:])
+        return rng.integers(97, 123, int(offs[-1]), dtype=np.uint8), None, None, offs
+    if name == "being.age":
+        mask = rng.random(n) >= 0.5
+        return rng.integers(0, 100, int(mask.sum()), dtype=np.int64).astype(np.int32), mask.astype(np.uint8), None, None
+    # friends.id / friends.age: 0-3 friends per row (as _examples/people/people.go:72), age null 50 %
+    k = rng.integers(0, 4, n)
+    nl = np.maximum(k, 1)
+    starts = np.zeros(n + 1, np.int64)
+    np.cumsum(nl, out=starts[1:])
+    total = int(starts[-1])
+    reps = np.ones(total, np.uint8)
+    reps[starts[:-1]] = 0
+    present = np.repeat(k > 0, nl)
+    if name == "friends.id":
+        defs = present.astype(np.uint8)
+        nv = int(present.sum())
+    else:
+        has_age = rng.random(total) >= 0.5
+        defs = present.astype(np.uint8) + (present & has_age).astype(np.uint8)
+        nv = int((defs == 2).sum())
+    return rng.integers(0, 100, nv, dtype=np.int64).astype(np.int32), defs, reps, None
+
+
+def build_file(workload, rg_ids, pages, rows_per_page):
+    """Synthetic file of one workload: returns (file bytes, Expect)."""
+    from parquet_amd import _native as N
+    from parquet_amd.writer import Column, ParquetWriter
+    cols = {"flat": _flat_cols(N, Column), "optional": _optional_cols(N, Column), "optint": _optional_cols(N, Column)[:1],
+            "optstr": _optional_cols(N, Column)[1:],
+            "nested": [c for c in _person_cols(N, Column) if c.path != "username"],
+            "mixed": _flat_cols(N, Column) + _optional_cols(N, Column) + _person_cols(N, Column)}[workload]
+    seed0 = {"flat": 1000, "optional": 2000, "optint": 2000, "optstr": 2000, "nested": 3000, "mixed": 5000}[workload]
     w = ParquetWriter(cols, stats=True)
-    for g in rg_ids:
-        rng = np.random.default_rng(3000 + g)
+    w.reserve(len(rg_ids) * pages * rows_per_page * sum(30 if c.phys_type == N.BYTE_ARRAY else 10 for c in cols) + (1 << 20))
+    ex = Expect()
+    for gi, g in enumerate(rg_ids):
+        rng = np.random.default_rng(seed0 + g)
+        keep = gi == 0 or gi == len(rg_ids) - 1
         w.begin_row_group()
         for ci, c in enumerate(cols):
             for _ in range(pages):
-                n = rows_per_page
-                if ci == 0:
-                    w.write_page(ci, rng.integers(0, 2**31 - 1, n, dtype=np.int64).astype(np.int32))
-                elif ci == 1:
-                    mask = rng.random(n) >= 0.5
-                    w.write_page(ci, rng.integers(0, 100, int(mask.sum()), dtype=np.int64).astype(np.int32), defs=mask.astype(np.uint8))
-                else:
-                    k = rng.integers(0, 4, n)                      # friends per row
-                    nl = np.maximum(k, 1)                          # levels per row
-                    starts = np.zeros(n + 1, np.int64)
-                    np.cumsum(nl, out=starts[1:])
-                    total = int(starts[-1])
-                    reps = np.ones(total, np.uint8)
-                    reps[starts[:-1]] = 0
-                    present = np.repeat(k > 0, nl)
-                    if ci == 2:
-                        defs = present.astype(np.uint8)
-                        nv = int(present.sum())
-                    else:
-                        has_age = rng.random(total) >= 0.5
-                        defs = present.astype(np.uint8) + (present & has_age).astype(np.uint8)
-                        nv = int((defs == 2).sum())
-                    w.write_page(ci, rng.integers(0, 100, nv, dtype=np.int64).astype(np.int32), defs=defs, reps=reps)
+                v, d, r, o = _gen_page(N, c.path, rng, rows_per_page)
+                w.write_page(ci, v, defs=d, reps=r, offsets=o)
+                ex.page(gi, ci, keep, v, d, r, o)
         w.end_row_group(pages * rows_per_page)
     buf = w.finish()
     w.close()
-    return buf
+    return buf, ex
 
 
-def cpu_baseline(buf, pf, seconds):
-    """The CPU oracle (a restatement of the reference's Go reader, one thread) over the first row group
-    of the same file, repeated until `seconds` have passed."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def verify(plan, pf, chunks, nc, ex):
+    """Checks a decoded batch against what the generator put into the file: level / value / char totals of
+    every chunk, and the full arrays of the first and the last row group."""
+    from parquet_amd import _native as N
+    ncol = pf.num_columns
+    for k in range(nc):
+        rg, ci = k // ncol, k % ncol
+        info = plan.info(k)
+        nl, nv, ch = ex.totals[(rg, ci)]
+        cd = chunks[k]
+        assert info.n_values == nv, ("values", rg, ci, info.n_values, nv)
+        if cd.max_def > 0:
+            assert info.n_levels == nl, ("levels", rg, ci, info.n_levels, nl)
+        if cd.phys_type == N.BYTE_ARRAY:
+            assert info.chars_bytes == ch, ("chars", rg, ci, info.chars_bytes, ch)
+        arr = ex.arrays.get((rg, ci))
+        if arr is None:
+            continue
+        if cd.max_def > 0:
+            assert np.array_equal(plan.fetch(k, N.OUT_DEFS), np.concatenate(arr["defs"])), ("defs", rg, ci)
+        if cd.max_rep > 0:
+            assert np.array_equal(plan.fetch(k, N.OUT_REPS), np.concatenate(arr["reps"])), ("reps", rg, ci)
+        vals = np.concatenate(arr["values"])
+        if cd.phys_type == N.BYTE_ARRAY:
+            assert np.array_equal(plan.fetch(k, N.OUT_CHARS), vals), ("chars", rg, ci)
+            offs = np.zeros(nv + 1, np.int64)
+            np.cumsum(np.concatenate(arr["lens"]), out=offs[1:])
+            assert np.array_equal(plan.fetch(k, N.OUT_OFFSETS, np.int32).astype(np.int64), offs), ("offsets", rg, ci)
+        else:
+            assert np.array_equal(plan.fetch(k, N.OUT_VALUES), vals), ("values", rg, ci)
+
+
+def _oracle_chunk(args):
     import oracle as O
-    metas = []
-    nbytes = 0
-    for c in range(pf.num_columns):
-        m = pf.chunk_meta(0, c)
-        ci = pf.columns[m["column"]][1]
-        metas.append((m, ci))
+    buf, m, phys, max_def, max_rep = args
+    ch = O.read_chunk(buf, m["start_pos"], phys, max_def, max_rep, m["num_values"], m["total_compressed_size"])
+    assert ch.error == 0
+    out = ch.values.size + ch.defs.size + ch.reps.size + (ch.offsets.size * 4 if ch.offsets is not None else 0)
+    return m["total_compressed_size"] + out  # headers are < 0.001 % of the payload
+
+
+def cpu_baseline(buf, pf, seconds, threads):
+    """The CPU oracle (a C restatement of the reference's Go reader) over the leading row groups of the same
+    file: column chunks in parallel on `threads` threads (the C code runs outside the interpreter lock), repeated
+    until `seconds` have passed."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import concurrent.futures as cf
+    n_rg = min(pf.num_row_groups, max(1, (2 * threads + pf.num_columns - 1) // pf.num_columns)) if threads > 1 else 1
+    tasks = []
+    for g in range(n_rg):
+        for c in range(pf.num_columns):
+            m = pf.chunk_meta(g, c)
+            ci = pf.columns[m["column"]][1]
+            tasks.append((buf, m, ci.phys_type, ci.max_def, ci.max_rep))
     t0 = time.perf_counter()
-    reps = 0
-    while True:
-        nbytes = 0
-        for m, ci in metas:
-            ch = O.read_chunk(buf, m["start_pos"], ci.phys_type, ci.max_def, ci.max_rep, m["num_values"],
-                              m["total_compressed_size"])
-            assert ch.error == 0
-            payload = m["total_compressed_size"]  # headers are < 0.001 % of it
-            out = ch.values.size + ch.defs.size + ch.reps.size + (ch.offsets.size * 4 if ch.offsets is not None else 0)
-            nbytes += payload + out
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= seconds:
-            break
-    return {"value": round(nbytes * reps / el / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": "first row group of the same file (%d column chunks, %.0f MB algorithmic) decoded %d times by the "
-                      "C restatement of the reference reader, one thread, %.1f s" % (len(metas), nbytes / 1e6, reps, el)}
+    reps, nbytes = 0, 0
+    with cf.ThreadPoolExecutor(max_workers=threads) as pool:
+        while True:
+            nbytes = sum(pool.map(_oracle_chunk, tasks)) if threads > 1 else sum(_oracle_chunk(t) for t in tasks)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= seconds:
+                break
+    return {"value": round(nbytes * reps / el / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": "first %d row group(s) of the same file (%d column chunks, %.0f MB algorithmic) decoded %d times by the C "
+                      "restatement of the reference reader, %d thread(s), chunks in parallel, %.1f s" % (n_rg, len(tasks), nbytes / 1e6, reps, threads, el)}
+
+
+DOMINANT = {"flat": "k_copy (PLAIN value gather)", "optint": "k_levels (single-pass level decode) beside k_copy",
+            "optional": "k_str_exits / k_str_mark (BYTE_ARRAY chain)", "optstr": "k_str_exits / k_str_mark (BYTE_ARRAY chain)",
+            "nested": "k_levels (single-pass level decode) and k_rows (row offsets)",
+            "mixed": "k_str_exits / k_str_mark (BYTE_ARRAY chain), k_levels and k_copy on two streams"}
+DESCRIBE = {
+    "mixed": "this GPU's share of configs[4]: configs[1]+[2]+[3] columns side by side (flat int32/int64/float64, optional int32 + string with "
+             "10%% nulls, Person{Being,Username,Friends []Being}), %d rows/page, %d page(s)/chunk, %d row groups per GPU (uncompressed DATA_PAGE v1)",
+    "flat": "configs[1]: flat required int32/int64/float64 columns, %d rows/page, %d pages/chunk, %d row groups per GPU (uncompressed DATA_PAGE v1, PLAIN)",
+    "optional": "configs[2]: optional int32 + string columns, 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
+    "nested": "configs[3]: Person{Being,Friends []Being} int32 leaves, %d rows/page, %d pages/chunk, %d row groups per GPU",
+    "optint": "configs[2], int32 half: optional int32 column, 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
+    "optstr": "configs[2], string half: optional string column (8-32 B), 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
+}
+DEFAULT_SHAPE = {"mixed": (1, 96), "flat": (64, 4), "optional": (8, 2), "optint": (8, 2), "optstr": (8, 2), "nested": (8, 2)}  # pages, row groups
+
+
+class Loaded:
+    """A workload resident on the device: file bytes in HBM and a decode plan over all its row groups."""
+
+    def __init__(self, ctx, workload, rg_ids, pages, rows_per_page):
+        from parquet_amd import _native as N
+        from parquet_amd import reader as R
+        self.N, self.ctx = N, ctx
+        self.buf, self.expect = build_file(workload, rg_ids, pages, rows_per_page)
+        self.pf = R.ParquetFile(self.buf)
+        self.chunks, self.nc, self.pgs, self.npg = self.pf.descriptors(0, self.pf.num_row_groups)
+        self.plan = R.Plan(ctx, self.chunks, self.nc, self.pgs, self.npg, self.pf.address, self.pf.size)
+        self.d_src = N.decode.pqd_device_alloc(ctx.handle, self.pf.size)
+        assert self.d_src
+        assert N.decode.pqd_copy_to_device(ctx.handle, self.d_src, self.pf.address, self.pf.size) == 0
+
+    def close(self):
+        self.plan.close()
+        self.N.decode.pqd_device_free(self.ctx.handle, self.d_src)
+
+
+def timed(ld, steps, warmup, before_step=None, barrier=None):
+    """W untimed steps, a check of the decoded batch, then K timed steps: returns (seconds, per-step device ms from the
+    HIP events on the decoder's stream, per-step ms of the PLAIN value gather)."""
+    import torch
+    for _ in range(max(warmup, 1)):
+        if before_step:
+            before_step()
+        ld.plan.run(ld.d_src)
+    ld.plan.sync()
+    torch.cuda.synchronize()
+    verify(ld.plan, ld.pf, ld.chunks, ld.nc, ld.expect)
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if before_step:
+            before_step()
+        ld.plan.run(ld.d_src)
+    ld.plan.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tot_ms, cp_ms = [], []
+    for k in range(min(steps, 256)):
+        a, b = ld.plan.run_ms(k)
+        tot_ms.append(a)
+        cp_ms.append(b)
+    return elapsed, float(np.mean(tot_ms)), float(np.mean(cp_ms))
 
 
 def main():
@@ -191,108 +315,56 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL unless --dist-backend gloo was asked for; an initialisation failure ends the run (no silent fallback)
         if args.dist_backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            except Exception as e:  # the collective is 8 bytes per rank: a CPU backend measures the same decode
-                print("bench: RCCL initialisation failed (%s), falling back to gloo" % e, file=sys.stderr, flush=True)
-                args.dist_backend = "gloo"
-                dist.init_process_group("gloo")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
     coll_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
 
-    from parquet_amd import _native as N
     from parquet_amd import reader as R
+    from parquet_amd import shard
 
-    builders = {"flat": build_flat_file, "optional": build_optional_file, "nested": build_nested_file,
-                "optint": lambda *a: build_optional_file(*a, which="int"),
-                "optstr": lambda *a: build_optional_file(*a, which="str")}
-    pages = args.pages or (64 if args.workload == "flat" else 8)
+    pages = args.pages or DEFAULT_SHAPE[args.workload][0]
     if args.row_groups is None:
-        args.row_groups = 4 if args.workload == "flat" else 2
+        args.row_groups = DEFAULT_SHAPE[args.workload][1]
     t_build = time.perf_counter()
     # The job's file has world * row_groups row groups (weak scaling); whole row groups go to ranks in
     # contiguous ranges balanced by payload bytes, and each rank materialises only its own shard.
-    from parquet_amd import shard
     first, count = shard.assign_row_groups([1] * (world * args.row_groups), world)[rank]
-    buf = builders[args.workload](list(range(first, first + count)), pages, args.rows_per_page)
-    pf = R.ParquetFile(buf)
-    t_build = time.perf_counter() - t_build
     ctx = R.Context(local_rank)
-    chunks, nc, pgs, npg = pf.descriptors(0, pf.num_row_groups)
-    plan = R.Plan(ctx, chunks, nc, pgs, npg, pf.address, pf.size)
-    d_src = N.decode.pqd_device_alloc(ctx.handle, pf.size)
-    assert d_src
-    assert N.decode.pqd_copy_to_device(ctx.handle, d_src, pf.address, pf.size) == 0
+    ld = Loaded(ctx, args.workload, list(range(first, first + count)), pages, args.rows_per_page)
+    t_build = time.perf_counter() - t_build
 
-    rows_local = torch.tensor([pf.num_rows], dtype=torch.int64, device=coll_dev)
+    rows_local = torch.tensor([ld.pf.num_rows], dtype=torch.int64, device=coll_dev)
     rows_all = torch.zeros(world, dtype=torch.int64, device=coll_dev)
 
-    def step():
-        if use_dist:
-            dist.all_gather_into_tensor(rows_all, rows_local)  # per-shard row counts → global row offsets
-        plan.run(d_src)
-
-    for _ in range(max(args.warmup, 1)):
-        step()
-    plan.sync()
-    torch.cuda.synchronize()
-
-    # sanity: the decoded first chunk equals the payload bytes it was decoded from
-    first_vals = plan.fetch(0, N.OUT_VALUES) if args.workload == "flat" else None
-    if first_vals is not None:
-        src = np.frombuffer(buf, np.uint8)
-        ok = True
-        o = 0
-        for p in range(chunks[0].first_page, chunks[0].first_page + chunks[0].n_pages):
-            a, l = pgs[p].src_off, pgs[p].payload_len
-            ok &= bool(np.array_equal(first_vals[o:o + l], src[a:a + l]))
-            o += l
-        assert ok and o == first_vals.size, "decoded values differ from the page payloads"
+    def gather_rows():  # per-shard row counts → global row offsets
+        dist.all_gather_into_tensor(rows_all, rows_local)
 
     steps = args.steps
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    plan.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, step_ms, cp_ms = timed(ld, steps, args.warmup, gather_rows if use_dist else None, dist.barrier if use_dist else None)
     if use_dist:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    bytes_in, bytes_out, copy_bytes = plan.bytes()
+    bytes_in, bytes_out, copy_bytes = ld.plan.bytes()
     alg = bytes_in + bytes_out
     alg_t = torch.tensor([alg], dtype=torch.int64, device=coll_dev)
     if use_dist:
         dist.all_reduce(alg_t)
     total_alg = int(alg_t.item())
 
-    # per-launch durations of the dominant kernel (PLAIN value gather) and of the whole run, from HIP
-    # events recorded on the decoder's own stream during the timed steps
-    n_ev = min(steps, 256)
-    tot_ms, cp_ms = [], []
-    for k in range(n_ev):
-        a, b = plan.run_ms(k)
-        tot_ms.append(a)
-        cp_ms.append(b)
-    cp_avg = float(np.mean(cp_ms))
-    achieved = copy_bytes / (cp_avg * 1e-3) / 1e9 if cp_avg > 0 and copy_bytes else 0.0
-
     if rank == 0:
         traffic = None
         try:
             tj = json.load(open(args.traffic_json))
-            key = "%s_p%d_g%d" % (args.workload, pages, args.row_groups)
-            traffic = tj.get(key)
+            traffic = tj.get("%s_p%d_g%d" % (args.workload, pages, args.row_groups))
         except Exception:
             pass
+        achieved = alg / (step_ms * 1e-3) / 1e9
         res = {
             "metric": "device-resident page decode GB/s (levels+PLAIN values), 1/2/4/8 MI355X",
             "value": round(total_alg * steps / elapsed / 1e9, 2),
@@ -307,40 +379,54 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": {
-                    "flat": "configs[1]: flat required int32/int64/float64 columns, %d rows/page, %d pages/chunk, %d row groups per GPU (uncompressed DATA_PAGE v1, PLAIN)",
-                    "optional": "configs[2]: optional int32 + string columns, 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
-                    "nested": "configs[3]: Person{Being,Friends []Being} int32 leaves, %d rows/page, %d pages/chunk, %d row groups per GPU",
-                    "optint": "configs[2], int32 half: optional int32 column, 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
-                    "optstr": "configs[2], string half: optional string column (8-32 B), 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
-                }[args.workload] % (args.rows_per_page, pages, args.row_groups),
-                "file_bytes_per_gpu": pf.size,
+                "workload": DESCRIBE[args.workload] % (args.rows_per_page, pages, args.row_groups),
+                "file_bytes_per_gpu": ld.pf.size,
                 "algorithmic_bytes_per_step_per_gpu": alg,
                 "sharding": "row groups per rank, no data-path collective; all_gather of row counts per step" if world > 1 else "single GPU",
             },
+            "collective": {"backend": ("rccl (torch nccl)" if args.dist_backend == "nccl" else "gloo") if use_dist else "none", "world": world},
+            # whole step: algorithmic bytes of one plan run / its device time (HIP events on the decoder's stream, average
+            # over the timed steps); a step is a fixed sequence of launches on two streams, so there is no single launch
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_copy (PLAIN value gather)",
+                "kernel": "whole step; dominant: " + DOMINANT[args.workload],
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "launch_ms_avg": round(cp_avg, 5),
-                "algorithmic_bytes_per_launch": copy_bytes,
+                "traffic_source": "PMC passes of an earlier profile run of this workload (profiles/traffic.json), not collected in this run" if traffic else None,
+                "step_ms_avg": round(step_ms, 5),
+                "algorithmic_bytes_per_step": alg,
+                "plain_gather": {"kernel": "k_copy", "launch_ms_avg": round(cp_ms, 5), "algorithmic_bytes_per_launch": copy_bytes,
+                                 "achieved": round(copy_bytes / (cp_ms * 1e-3) / 1e9, 1) if cp_ms > 0 and copy_bytes else 0.0,
+                                 "note": "runs beside the level and string kernels on a second stream"},
             },
-            "device_ms_per_step_events": round(float(np.mean(tot_ms)), 4),
+            "device_ms_per_step_events": round(step_ms, 4),
             "setup_seconds": round(t_build, 1),
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on a single-GPU run only
-            res["cpu_baseline"] = cpu_baseline(buf, pf, args.cpu_seconds)
+        if world == 1 and not args.no_cpu_baseline:  # the CPU legs are timed on a single-GPU run only
+            threads = max(1, min(16, len(os.sched_getaffinity(0))))
+            res["cpu_baseline"] = cpu_baseline(ld.buf, ld.pf, args.cpu_seconds, 1)
+            res["cpu_baseline_all_cores"] = cpu_baseline(ld.buf, ld.pf, args.cpu_seconds, threads)
         if args.pcie:
-            res["pcie_inclusive"] = pcie_inclusive(ctx, plan, pf, d_src, alg)
-            res["pcie_overlapped"] = pcie_overlapped(pf, local_rank, alg)
+            res["pcie_inclusive"] = pcie_inclusive(ctx, ld.plan, ld.pf, ld.d_src, alg)
+            res["pcie_overlapped"] = pcie_overlapped(ld.pf, local_rank, alg)
+    ld.close()
+    if rank == 0:
+        if world == 1 and not args.no_extras and args.workload == "mixed":
+            # the single-config workloads on smaller files, same run, same checks
+            extras = {}
+            for wl, (pg, rgs) in (("flat", (16, 2)), ("optint", (16, 2)), ("optstr", (8, 2)), ("nested", (8, 2))):
+                e = Loaded(ctx, wl, list(range(rgs)), pg, args.rows_per_page)
+                el, sm, _ = timed(e, 50, 3)
+                bi, bo, _ = e.plan.bytes()
+                extras[wl] = {"value": round((bi + bo) * 50 / el / 1e9, 1), "unit": "GB/s", "ms_per_step": round(el / 50 * 1e3, 4),
+                              "roofline_frac": round((bi + bo) / (sm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "shape": "%d pages/chunk, %d row groups" % (pg, rgs)}
+                e.close()
+            res["per_workload"] = extras
         print(json.dumps(res), flush=True)
-
-    plan.close()
-    N.decode.pqd_device_free(ctx.handle, d_src)
     ctx.close()
     if use_dist:
         dist.destroy_process_group()

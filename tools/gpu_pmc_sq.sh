@@ -6,7 +6,7 @@ R="$GRAFT_REPO_ROOT"; W=${1:-optstr}; P=${2:-8}
 D="$R/gpurun_out/pmc_$W"
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$D"; mkdir -p "$D"
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$D" -- python3 "$R/bench.py" --workload $W --pages $P --steps 3 --warmup 1 --no-cpu-baseline > "$D/run.log" 2>&1 || { tail -20 "$D/run.log"; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$D" -- python3 "$R/bench.py" --workload $W --pages $P --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$D/run.log" 2>&1 || { tail -20 "$D/run.log"; exit 1; }
 python3 - "$D" <<'PY'
 import csv,glob,sys,collections
 f=glob.glob(sys.argv[1]+"/*/*_counter_collection.csv")[0]

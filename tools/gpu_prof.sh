@@ -5,7 +5,7 @@ set -o pipefail
 R="$GRAFT_REPO_ROOT"; W=${1:-optional}; P=${2:-8}
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$R/gpurun_out/prof_$W"; mkdir -p "$R/gpurun_out/prof_$W"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$W" -- python3 "$R/bench.py" --workload $W --pages $P --steps 10 --warmup 2 --no-cpu-baseline > "$R/gpurun_out/prof_$W/run.log" 2>&1 || { tail -20 "$R/gpurun_out/prof_$W/run.log"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$W" -- python3 "$R/bench.py" --workload $W --pages $P --steps 10 --warmup 2 --no-cpu-baseline --no-extras > "$R/gpurun_out/prof_$W/run.log" 2>&1 || { tail -20 "$R/gpurun_out/prof_$W/run.log"; exit 1; }
 python3 - "$R/gpurun_out/prof_$W" <<'PY'
 import csv,glob,sys
 f=glob.glob(sys.argv[1]+"/*/*_kernel_stats.csv")[0]

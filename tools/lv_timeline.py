@@ -23,9 +23,7 @@ NAMES = ["start", "loaded", "sweep", "groups", "exits", "entry known", "publishe
 def main():
     workload = sys.argv[1] if len(sys.argv) > 1 else "optint"
     pages = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-    builders = {"nested": bench.build_nested_file, "optint": lambda *a: bench.build_optional_file(*a, which="int"),
-                "optstr": lambda *a: bench.build_optional_file(*a, which="str")}
-    buf = builders[workload]([0, 1], pages, 1_000_000)
+    buf, _ = bench.build_file(workload, [0, 1], pages, 1_000_000)
     pf = R.ParquetFile(buf)
     ctx = R.Context(0)
     chunks, nc, pgs, npg = pf.descriptors(0, pf.num_row_groups)
