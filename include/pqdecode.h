@@ -75,7 +75,12 @@ typedef enum {
     PQD_OUT_ROW_LEVEL_OFF = 7,/* int32[n_rows+1] — first level of each row (write_repeated.go:62-80); only for
                                  repeated columns (max_rep > 0): otherwise row r is level r and its value index is
                                  the number of set validity bits before r */
-    PQD_OUT_ROW_VALUE_OFF = 8 /* int32[n_rows+1] — first value of each row; repeated columns only */
+    PQD_OUT_ROW_VALUE_OFF = 8,/* int32[n_rows+1] — first value of each row; repeated columns only */
+    PQD_OUT_VALUE_INDEX = 9   /* uint32[ceil(n_levels/64)+1] — per 64 levels, the non-null levels in front of them (valsFromDefs
+                                 per level, fields.go:216-228): the value of non-null level i of an optional column, which the
+                                 generated write functions consume row by row (performance/parquet.go:104-113), is
+                                 values[VALUE_INDEX[i/64] + popcount(VALIDITY bits of word i/64 below bit i%64)]; the last
+                                 entry is n_values.  Columns with definition levels only */
 } pqd_output;
 
 typedef struct {

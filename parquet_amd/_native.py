@@ -19,7 +19,7 @@ STATUS_NAMES = {0: "OK", -1: "E_ARG", -2: "E_HIP", -3: "E_NOMEM", -4: "E_FORMAT"
 BOOLEAN, INT32, INT64, INT96, FLOAT, DOUBLE, BYTE_ARRAY, FIXED_LEN_BYTE_ARRAY = range(8)
 
 (OUT_DEFS, OUT_REPS, OUT_VALUES, OUT_OFFSETS, OUT_CHARS, OUT_VALIDITY, OUT_PAGE_NONNULL,
- OUT_ROW_LEVEL_OFF, OUT_ROW_VALUE_OFF) = range(9)
+ OUT_ROW_LEVEL_OFF, OUT_ROW_VALUE_OFF, OUT_VALUE_INDEX) = range(10)
 
 
 class ChunkDesc(C.Structure):

@@ -40,7 +40,8 @@ int fail(pqd_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess) {
 
 #define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((ctx), PQD_E_HIP, #call, e_); } while (0)
 
-struct OutPtrs { u8* p[9]; size_t cap[9]; };
+constexpr int N_OUT = 10;  // pqd_output values
+struct OutPtrs { u8* p[N_OUT]; size_t cap[N_OUT]; };
 
 }  // namespace
 
@@ -60,6 +61,9 @@ struct pqd_plan {
     std::vector<u32> seg_blk_prefix;
     std::vector<u32> bool_pages, btile_prefix, row_chunks, rtile_prefix;
     std::vector<u32> stile_region;  // region of every string chain tile
+    std::vector<u32> vidx_pages;    // pages of the chunks that have definition levels
+    std::vector<u64> page_lvl_off;  // level index of every page's first level within its chunk
+    u32* d_vidx_pages = nullptr; u64* d_lvl_off = nullptr;
     std::vector<OutPtrs> outs;
     std::vector<int> chunk_width;
 
@@ -294,6 +298,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
             P.pad = 0;
             payload_off[pi] = (u64)pd.src_off;
             lvl_off[pi] = levels;
+            if (cd.max_def > 0) pl->vidx_pages.push_back((u32)pi);
             val_stream_off[pi] = stream;
             levels += (u64)pd.num_values;
             stream += P.val_len;
@@ -316,17 +321,18 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
 
     // ---- size the outputs and the scratch tables
     ArenaPlan ap;
-    std::vector<size_t> off_out(n_chunks * 9, (size_t)-1);
+    std::vector<size_t> off_out(n_chunks * N_OUT, (size_t)-1);
     pl->outs.resize(n_chunks);
     for (size_t c = 0; c < n_chunks; c++) {
         const ChunkRec& C = pl->chunks[c];
-        size_t* o = &off_out[c * 9];
+        size_t* o = &off_out[c * N_OUT];
         size_t* cap = pl->outs[c].cap;
         memset(cap, 0, sizeof pl->outs[c].cap);
         auto want = [&](int which, size_t bytes) { cap[which] = bytes; o[which] = ap.take(bytes + 64); };
         if (C.max_def > 0) {
             want(PQD_OUT_DEFS, C.n_levels);
             cap[PQD_OUT_VALIDITY] = (C.n_levels + 7) / 8;  // placed in the range that is zeroed before every run (below)
+            want(PQD_OUT_VALUE_INDEX, ((C.n_levels + 63) / 64 + 1) * 4);
         }
         if (C.max_rep > 0) {
             want(PQD_OUT_REPS, C.n_levels);
@@ -424,6 +430,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_lreg = ap.take(pl->lregions.size() * sizeof(Region));
     const size_t o_sreg = ap.take(pl->sregions.size() * sizeof(Region));
     const size_t o_lvo = ap.take(pl->lv_order.size() * sizeof(LvTile));
+    pl->page_lvl_off.assign(lvl_off.begin(), lvl_off.end());
+    const size_t o_vip = ap.take(pl->vidx_pages.size() * 4), o_plo = ap.take(n_pages * 8);
     const size_t o_sctp = ap.take(pl->stile_chain_prefix.size() * 4);
     const size_t o_str = ap.take(pl->stile_region.size() * 4);
     const size_t o_sgp = ap.take(pl->sgroup_prefix.size() * 4);
@@ -459,7 +467,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_pdyn = ap.take(n_pages * sizeof(PageDyn));
     // validity bitmaps: the level kernel ORs the words that two workgroups share
     for (size_t c = 0; c < n_chunks; c++)
-        if (pl->chunks[c].max_def > 0) off_out[c * 9 + PQD_OUT_VALIDITY] = ap.take(pl->outs[c].cap[PQD_OUT_VALIDITY] + 64);
+        if (pl->chunks[c].max_def > 0) off_out[c * N_OUT + PQD_OUT_VALIDITY] = ap.take(pl->outs[c].cap[PQD_OUT_VALIDITY] + 64);
     const size_t o_status = ap.take(16);
     const size_t o_lvticket = ap.take(16);
     const size_t o_lvpos = ap.take((size_t)pl->n_lvtiles * 8), o_lvval = ap.take((size_t)pl->n_lvtiles * 8);  // hand-off granules
@@ -480,10 +488,10 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     // patch pointers
     for (size_t c = 0; c < n_chunks; c++) {
         ChunkRec& C = pl->chunks[c];
-        u8** ptrs[9] = {&C.defs, &C.reps, &C.values, &C.offsets, &C.chars, &C.validity, &C.page_nonnull,
-                        &C.row_level_off, &C.row_value_off};
-        for (int w = 0; w < 9; w++) {
-            const size_t o = off_out[c * 9 + w];
+        u8** ptrs[N_OUT] = {&C.defs, &C.reps, &C.values, &C.offsets, &C.chars, &C.validity, &C.page_nonnull,
+                            &C.row_level_off, &C.row_value_off, &C.value_index};
+        for (int w = 0; w < N_OUT; w++) {
+            const size_t o = off_out[c * N_OUT + w];
             *ptrs[w] = o == (size_t)-1 ? nullptr : A + o;
             pl->outs[c].p[w] = *ptrs[w];
         }
@@ -556,6 +564,9 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if ((rc = upload(ctx, pl->d_lregions, pl->lregions))) return rc;
     if ((rc = upload(ctx, pl->d_sregions, pl->sregions))) return rc;
     if ((rc = upload(ctx, (LvTile*)(A + o_lvo), pl->lv_order))) return rc;
+    pl->d_vidx_pages = (u32*)(A + o_vip); pl->d_lvl_off = (u64*)(A + o_plo);
+    if ((rc = upload(ctx, pl->d_vidx_pages, pl->vidx_pages))) return rc;
+    if ((rc = upload(ctx, pl->d_lvl_off, pl->page_lvl_off))) return rc;
     if ((rc = upload(ctx, pl->d_stile_chain_prefix, pl->stile_chain_prefix))) return rc;
     if ((rc = upload(ctx, (u32*)(A + o_str), pl->stile_region))) return rc;
     if ((rc = upload(ctx, pl->d_sgroup_prefix, pl->sgroup_prefix))) return rc;
@@ -611,6 +622,7 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     // levels
     if (n_lreg) HIP_TRY(ctx, launch_levels(st, src, pl->lv));
     HIP_TRY(ctx, launch_page_scan(st, pl->d_chunks, n_chunks, pl->d_pages, n_pages, pl->d_page_dyn, pl->d_chunk_dyn, pl->d_status));
+    HIP_TRY(ctx, launch_value_index(st, pl->d_chunks, pl->d_pages, pl->d_page_dyn, pl->d_vidx_pages, (u32)pl->vidx_pages.size(), pl->d_lvl_off));
     HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, (u32)pl->bool_pages.size(), pl->n_btiles,
                               pl->d_chunks, pl->d_page_dyn, pl->d_status));
     if (n_sreg) {
@@ -732,12 +744,12 @@ int pqd_plan_bytes(pqd_plan* pl, int64_t* bytes_in, int64_t* bytes_out, int64_t*
 }
 
 const void* pqd_plan_device_ptr(pqd_plan* pl, size_t c, pqd_output which) {
-    if (!pl || c >= pl->chunks.size() || (int)which < 0 || (int)which > 8) return nullptr;
+    if (!pl || c >= pl->chunks.size() || (int)which < 0 || (int)which >= N_OUT) return nullptr;
     return pl->outs[c].p[which];
 }
 
 int64_t pqd_plan_fetch(pqd_plan* pl, size_t c, pqd_output which, void* dst, size_t cap) {
-    if (!pl || c >= pl->chunks.size() || (int)which < 0 || (int)which > 8 || !pl->synced) return PQD_E_ARG;
+    if (!pl || c >= pl->chunks.size() || (int)which < 0 || (int)which >= N_OUT || !pl->synced) return PQD_E_ARG;
     pqd_ctx* ctx = pl->ctx;
     const u8* p = pl->outs[c].p[which];
     if (!p) return 0;
@@ -753,6 +765,7 @@ int64_t pqd_plan_fetch(pqd_plan* pl, size_t c, pqd_output which, void* dst, size
     case PQD_OUT_VALIDITY: n = ((size_t)ci.n_levels + 7) / 8; break;
     case PQD_OUT_PAGE_NONNULL: n = (size_t)ci.n_pages * 8; break;
     case PQD_OUT_ROW_LEVEL_OFF: case PQD_OUT_ROW_VALUE_OFF: n = ((size_t)ci.n_rows + 1) * 4; break;
+    case PQD_OUT_VALUE_INDEX: n = (((size_t)ci.n_levels + 63) / 64 + 1) * 4; break;
     }
     if (n > pl->outs[c].cap[which]) n = pl->outs[c].cap[which];
     if (n > cap) return fail(ctx, PQD_E_ARG, "destination too small");

@@ -98,7 +98,7 @@ struct ChunkRec {
     u64 n_levels;
     u64 stream_len;   // sum of the pages' values-region lengths
     u64 req_values;   // required chunk: parquet.Page.N, the number of values the typed Read takes
-    u8 *defs, *reps, *values, *offsets, *chars, *validity, *page_nonnull, *row_level_off, *row_value_off;
+    u8 *defs, *reps, *values, *offsets, *chars, *validity, *page_nonnull, *row_level_off, *row_value_off, *value_index;
 };
 struct ChunkDyn {
     u64 n_values, chars, n_rows;
@@ -174,6 +174,9 @@ hipError_t launch_rle_decode_u8(hipStream_t st, void* scratch, int width, const 
 
 hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks, const PageRec* pages, u32 n_pages,
                             PageDyn* page_dyn, ChunkDyn* chunk_dyn, int* status);
+// value index: per 64 levels of a chunk, the number of non-null levels in front of them (one workgroup per page)
+hipError_t launch_value_index(hipStream_t st, const ChunkRec* chunks, const PageRec* pages, const PageDyn* page_dyn,
+                              const u32* page_ids, u32 n_pages, const u64* page_lvl_off);
 hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids, const u32* btile_prefix,
                         u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn, const int* status);
 hipError_t launch_str_check(hipStream_t st, const PageRec* pages, const ChunkRec* chunks, const PageDyn* page_dyn,

@@ -1621,12 +1621,63 @@ __global__ __launch_bounds__(64) void k_page_scan(const ChunkRec* __restrict__ c
         chunk_dyn[c].n_values = run_vals;
         chunk_dyn[c].chars = run_chars;
         if (C.max_def > 0 && C.max_rep == 0) chunk_dyn[c].n_rows = C.n_levels;  // not repeated: every level is a row
+        if (C.max_def > 0) ((u32*)C.value_index)[(C.n_levels + 63) >> 6] = (u32)run_vals;  // the total closes the value index
         if (C.phys_type == PT_BYTE_ARRAY) {
             if (run_chars > 0x7fffffffull) set_status(status, ST_UNSUPPORTED, c);
             else ((int32_t*)C.offsets)[run_vals] = (int32_t)run_chars;
         }
         // binary.Read of n_values*w bytes from the concatenated values regions (io.ReadFull)
         if (C.width_bytes > 0 && run_vals * C.width_bytes > C.stream_len) set_status(status, ST_CORRUPT, c);
+    }
+}
+
+// =====================================================================================
+// k_value_index — the dense value index of the optional levels (valsFromDefs per level, fields.go:216-228; what
+// the generated write functions do per row when they take `vals[0]` only for def == max, performance/parquet.go:104-113):
+// value_index[w] = number of levels with def == max_def among the chunk's levels [0, 64 w), so the value of a
+// non-null level i is values[value_index[i / 64] + popcount(validity bits of word i / 64 below bit i % 64)].
+// One workgroup per page: it owns the 64-level words that START inside the page; the page's first value index
+// comes from k_page_scan.  Entry ceil(n_levels / 64) (the total) is written by k_page_scan.
+// =====================================================================================
+__global__ __launch_bounds__(1024) void k_value_index(const ChunkRec* __restrict__ chunks, const PageRec* __restrict__ pages,
+                                                      const PageDyn* __restrict__ page_dyn, const u32* __restrict__ page_ids,
+                                                      const u64* __restrict__ page_lvl_off) {
+    __shared__ u32 s_w[16], s_carry;
+    const u32 pg = page_ids[blockIdx.x];
+    const PageRec P = pages[pg];
+    const ChunkRec C = chunks[P.chunk];
+    const u64 l0 = page_lvl_off[pg], l1 = l0 + P.num_values;      // the page's levels within the chunk
+    const u64 w0 = (l0 + 63) >> 6, w1 = (l1 + 63) >> 6;            // words that start inside the page
+    if (w0 >= w1) return;
+    const u64* const vb = (const u64*)C.validity;                 // 256-byte aligned, padded past its last word
+    u32* const out = (u32*)C.value_index;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) {
+        // valid levels of the page in front of word w0: the upper part of word w0 - 1
+        u32 head = 0;
+        if (l0 & 63) head = __popcll(vb[w0 - 1] >> (l0 & 63));
+        s_carry = (u32)page_dyn[pg].val_off + head;
+    }
+    __syncthreads();
+    for (u64 base = w0; base < w1; base += 1024) {
+        const u64 w = base + tid;
+        const u32 c = w < w1 ? (u32)__popcll(vb[w]) : 0;
+        u32 incl = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(incl, d);
+            if (lane >= (u32)d) incl += t;
+        }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        u32 before = s_carry, total = 0;
+#pragma unroll
+        for (u32 q = 0; q < 16; q++) {
+            if (q < wv) before += s_w[q];
+            total += s_w[q];
+        }
+        if (w < w1) out[w] = before + incl - c;
+        __syncthreads();
+        if (tid == 0) s_carry += total;
     }
 }
 
@@ -2194,6 +2245,14 @@ hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks
                             PageDyn* page_dyn, ChunkDyn* chunk_dyn, int* status) {
     if (n_chunks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_page_scan, dim3(n_chunks), dim3(64), 0, st, chunks, n_chunks, pages, page_dyn, chunk_dyn, status);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_value_index(hipStream_t st, const ChunkRec* chunks, const PageRec* pages, const PageDyn* page_dyn,
+                              const u32* page_ids, u32 n_pages, const u64* page_lvl_off) {
+    if (n_pages == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_value_index, dim3(n_pages), dim3(1024), 0, st, chunks, pages, page_dyn, page_ids, page_lvl_off);
     LAUNCH_CHECK();
     return hipSuccess;
 }

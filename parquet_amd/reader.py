@@ -172,6 +172,7 @@ class Plan:
             N.OUT_OFFSETS: (ci.n_values + 1) * 4, N.OUT_CHARS: ci.chars_bytes,
             N.OUT_VALIDITY: (ci.n_levels + 7) // 8, N.OUT_PAGE_NONNULL: ci.n_pages * 8,
             N.OUT_ROW_LEVEL_OFF: (ci.n_rows + 1) * 4, N.OUT_ROW_VALUE_OFF: (ci.n_rows + 1) * 4,
+            N.OUT_VALUE_INDEX: ((ci.n_levels + 63) // 64 + 1) * 4,
         }
         if not self.device_ptr(chunk, which):
             return np.zeros(0, dtype)
@@ -197,7 +198,7 @@ class Plan:
             # non-null levels before it
             n = out["defs"].size
             out["row_level_off"] = np.arange(n + 1, dtype=np.int64)
-            out["row_value_off"] = np.concatenate(([0], np.cumsum(out["defs"] == cd.max_def, dtype=np.int64)))
+            out["row_value_off"] = value_offsets(out["validity"], self.fetch(chunk, N.OUT_VALUE_INDEX, np.uint32), n)
         out["sizes"] = self.fetch(chunk, N.OUT_PAGE_NONNULL, np.int64)
         if cd.phys_type == N.BYTE_ARRAY:
             out["offsets"] = self.fetch(chunk, N.OUT_OFFSETS, np.int32)
@@ -218,6 +219,20 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+def value_offsets(validity, value_index, n_levels):
+    """First value of every row of a non-repeated optional column (row r = level r), n_levels + 1 entries, from the
+    device's two products: the validity bitmap and the value index (non-null levels in front of every 64-level
+    word): word base + set bits of the word below the level."""
+    bits = np.unpackbits(validity, bitorder="little")[:n_levels].astype(np.int64)
+    pad = (-n_levels) % 64
+    words = np.concatenate((bits, np.zeros(pad, np.int64))).reshape(-1, 64)
+    within = np.cumsum(words, axis=1) - words            # set bits of the word below each level
+    out = np.empty(n_levels + 1, np.int64)
+    out[:n_levels] = (value_index[:words.shape[0], None].astype(np.int64) + within).reshape(-1)[:n_levels]
+    out[n_levels] = int(value_index[(n_levels + 63) // 64])
+    return out
 
 
 def decode_host(ctx, chunks, n_chunks, pages, n_pages, src_addr, src_len):

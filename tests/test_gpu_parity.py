@@ -742,3 +742,28 @@ def test_decode_rejects_uncompressed_page_outside_the_host_buffer_in_a_mixed_cod
     with pytest.raises(N.PqdError) as e:
         R.decode_host(ctx, cv, nc, pv, npg, pf.address, pf.size)
     assert e.value.code == N.E_CORRUPT
+
+
+def test_value_index_scatters_dense_values_to_their_rows(ctx):
+    """PQD_OUT_VALUE_INDEX + the validity bitmap give every non-null level its dense value in O(1): the per-row
+    consumption of the generated write functions (performance/parquet.go:104-113).  Pages of sizes that are no
+    multiple of 64, so 64-level words straddle pages."""
+    rng = np.random.default_rng(21)
+    n = 10007
+    vals = rng.integers(-2**31, 2**31 - 1, n, dtype=np.int64).astype(np.int32)
+    mask = rng.random(n) >= 0.3
+    buf = write_flat_table([Column("a", N.INT32, [1])], [(vals, mask)], n, 999)
+    pf = R.ParquetFile(buf)
+    chunks, nc, pages, npg = pf.descriptors(0, 1)
+    plan = R.decode_host(ctx, chunks, nc, pages, npg, pf.address, pf.size)
+    try:
+        vi = plan.fetch(0, N.OUT_VALUE_INDEX, np.uint32)
+        bits = np.unpackbits(plan.fetch(0, N.OUT_VALIDITY), bitorder="little")[:n].astype(bool)
+        dense = plan.fetch(0, N.OUT_VALUES, np.int32)
+        assert vi.size == (n + 63) // 64 + 1 and vi[-1] == mask.sum() == dense.size
+        assert np.array_equal(vi[:-1], np.concatenate(([0], np.cumsum(mask)))[0:n:64])
+        rows = np.nonzero(bits)[0]
+        below = np.array([bin(int.from_bytes(np.packbits(bits[(i // 64) * 64:i], bitorder="little").tobytes(), "little")).count("1") for i in rows[:500]])
+        assert np.array_equal(dense[vi[rows[:500] // 64] + below], vals[rows[:500]])
+    finally:
+        plan.close()
