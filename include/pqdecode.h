@@ -293,6 +293,42 @@ int pqd_file_chunk_codec(const pqd_file* f, int32_t rg, int32_t chunk);
  *        file position of the chunk's first page header, index of its first walked page, pages walked}. */
 int pqd_file_chunk_meta(const pqd_file* f, int32_t rg, int32_t chunk, int64_t out[6]);
 
+/* ---- multi-GPU: whole row groups per GPU ---------------------------------------------------------
+ * Nothing in the reference corresponds to this (it is one goroutine on one host); what makes it possible is
+ * that readRowGroup starts every row group from fresh Field objects (cmd/parquetgen/gen/template.go:329), so row
+ * groups are independent.  GPUs take contiguous ranges of row groups balanced by payload bytes, decode them with
+ * no data-path exchange, and only exchange their row counts to learn their global row offsets. */
+
+/* Contiguous ranges [first[r], first[r] + count[r]) of n weighted items for `world` ranks: cut r lies at the item
+ * boundary nearest to r/world of the total weight.  Host only. */
+int pqd_shard_assign(const int64_t* weights, int32_t n, int32_t world, int32_t* first, int32_t* count);
+/* The same over the row groups of a file, weighted by their chunks' total_compressed_size (parquet.go:197). */
+int pqd_file_shard(const pqd_file* f, int32_t world, int32_t* first, int32_t* count);
+
+/* One process, several GPUs: one context and one host thread per device (a device may be listed more than once:
+ * then its shards run on separate contexts). */
+typedef struct pqd_multi pqd_multi;
+int pqd_multi_create(const int* devices, int n, pqd_multi** out);
+void pqd_multi_destroy(pqd_multi* m);
+/* Walks the file, assigns its row groups, decodes every shard on its device (pqd_decode, all shards at once) and
+ * scans the shards' row counts.  Returns the first shard error, if any. */
+int pqd_multi_decode_file(pqd_multi* m, const void* buf, size_t len);
+int pqd_multi_shards(const pqd_multi* m);
+/* Row group range, rows, global row offset (rows of the shards before it) and decoded plan of one shard; the plan
+ * (NULL for a shard without row groups) belongs to the object and lives until the next decode or destroy. */
+int pqd_multi_shard(const pqd_multi* m, int shard, int32_t* rg_first, int32_t* rg_count, int64_t* rows, int64_t* row_offset,
+                    pqd_plan** plan);
+const char* pqd_multi_last_error(const pqd_multi* m);
+
+/* One process per GPU: the row counts go through RCCL (ncclAllGather of one int64 per rank, xGMI inside a node).
+ * librccl is loaded on first use (PQD_E_UNSUPPORTED when it is absent).  Rank 0 makes the 128-byte id and hands it
+ * to the other ranks by whatever means the host program has; `comm` is an ncclComm_t. */
+int pqd_rccl_unique_id(void* id128);
+int pqd_rccl_comm_create(int device, int rank, int world, const void* id128, void** comm);
+void pqd_rccl_comm_destroy(void* comm);
+/* all_rows: host array of `world` entries; *row_offset = rows of the ranks in front of this one. */
+int pqd_rccl_gather_rows(int device, void* comm, int rank, int world, int64_t local_rows, int64_t* all_rows, int64_t* row_offset);
+
 #ifdef __cplusplus
 }
 #endif

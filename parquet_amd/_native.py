@@ -107,6 +107,18 @@ DECODE_SYMBOLS = {
     "pqd_file_page_header": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "pqd_file_chunk_codec": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "pqd_file_chunk_meta": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    "pqd_shard_assign": (C.c_int, [C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "pqd_file_shard": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "pqd_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
+    "pqd_multi_destroy": (None, [_P]),
+    "pqd_multi_decode_file": (C.c_int, [_P, _P, C.c_size_t]),
+    "pqd_multi_shards": (C.c_int, [_P]),
+    "pqd_multi_shard": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(_P)]),
+    "pqd_multi_last_error": (C.c_char_p, [_P]),
+    "pqd_rccl_unique_id": (C.c_int, [_P]),
+    "pqd_rccl_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    "pqd_rccl_comm_destroy": (None, [_P]),
+    "pqd_rccl_gather_rows": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
 SYNTH_SYMBOLS = {

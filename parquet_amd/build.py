@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
 
-DECODE_SOURCES = ["pqd_kernels.hip", "pqd_levels.hip", "pqd_encode.hip", "pqd_api.cpp", "pqd_file.cpp"]
+DECODE_SOURCES = ["pqd_kernels.hip", "pqd_levels.hip", "pqd_encode.hip", "pqd_api.cpp", "pqd_file.cpp", "pqd_multi.cpp"]
 DECODE_DEPS = DECODE_SOURCES + ["pqd_device.h", "pqd_rle.h", "thrift_compact.h", os.path.join("..", "..", "include", "pqdecode.h")]
 SYNTH_SOURCES = ["pqd_writer.cpp"]
 SYNTH_DEPS = SYNTH_SOURCES + ["thrift_compact.h"]
@@ -34,7 +34,7 @@ def build_all(force=False):
     if force or _stale(decode, DECODE_DEPS):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-              "-Wno-unused-function", "-o", decode] + DECODE_SOURCES)
+              "-Wno-unused-function", "-o", decode] + DECODE_SOURCES + ["-ldl", "-lpthread"])
     synth = os.path.join(LIB, "libpqsynth.so")
     if force or _stale(synth, SYNTH_DEPS):
         _run([os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", synth] + SYNTH_SOURCES)

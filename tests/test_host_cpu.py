@@ -252,3 +252,23 @@ def test_reference_fixture_headers():
     import json
     g = json.load(open(p))
     assert g["first_header_hex"].startswith("150015a00615aa062c15c8011500150615060000")
+
+
+def test_c_partitioner_matches_shard_py():
+    """pqd_shard_assign (the partitioner below the C ABI) against parquet_amd.shard.assign_row_groups."""
+    import ctypes as C
+    from parquet_amd import shard
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        n = int(rng.integers(0, 40))
+        world = int(rng.integers(1, 10))
+        kind = int(rng.integers(0, 3))
+        w = [1] * n if kind == 0 else [int(x) for x in rng.integers(0, 1000, n)] if kind == 1 else [int(x) for x in rng.integers(10**6, 10**9, n)]
+        arr = (C.c_int64 * max(n, 1))(*w)
+        first = (C.c_int32 * world)()
+        count = (C.c_int32 * world)()
+        assert N.decode.pqd_shard_assign(arr, n, world, first, count) == 0
+        got = [(first[r], count[r]) for r in range(world)]
+        assert got == shard.assign_row_groups(w, world), (w, world)
+        assert sum(c for _, c in got) == n and all(got[r][0] + got[r][1] == got[r + 1][0] for r in range(world - 1))
+    assert N.decode.pqd_shard_assign(None, 3, 2, (C.c_int32 * 2)(), (C.c_int32 * 2)()) == N.E_ARG
