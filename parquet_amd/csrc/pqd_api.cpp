@@ -18,7 +18,8 @@ using namespace pqd;
 struct pqd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // side stream of the PLAIN value gather
+    hipStream_t stream2 = nullptr;  // side stream of the first pass over the strings
+    hipStream_t stream3 = nullptr;  // side stream of the PLAIN value gather
     bool overlap = true;            // PQD_OVERLAP=0 keeps everything on one stream
     bool graph = false;             // PQD_GRAPH=1 replays chain batches as a captured HIP graph
     std::string err;
@@ -94,7 +95,8 @@ struct pqd_plan {
     static constexpr int EV_RING = 256;
     hipEvent_t ev[EV_RING][4] = {};
     hipEvent_t ev_fork = nullptr;  // orders the value gather's side stream after the run start
-    hipEvent_t ev_join = nullptr;  // ... and the run's end after the gather (graph capture)
+    hipEvent_t ev_join = nullptr;  // ... the strings' marking pass after their first pass
+    hipEvent_t ev_join_copy = nullptr;  // ... and the run's end after the gather
     hipGraphExec_t gexec = nullptr;  // captured run (see pqd_plan_run)
     const u8* gsrc = nullptr;        // the source pointer the graph was captured with
     uint64_t runs = 0;
@@ -141,8 +143,10 @@ int pqd_create(int device, pqd_ctx** out) {
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess) {
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
         delete ctx;
         return PQD_E_HIP;
     }
@@ -150,6 +154,7 @@ int pqd_create(int device, pqd_ctx** out) {
     if (lv_scratch_init(device) != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
         (void)hipStreamDestroy(ctx->stream2);
+        (void)hipStreamDestroy(ctx->stream3);
         delete ctx;
         return PQD_E_HIP;
     }
@@ -168,6 +173,7 @@ void pqd_destroy(pqd_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     delete ctx;
 }
 
@@ -218,6 +224,7 @@ void pqd_plan_destroy(pqd_plan* pl) {
             if (e) (void)hipEventDestroy(e);
     if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
     if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
+    if (pl->ev_join_copy) (void)hipEventDestroy(pl->ev_join_copy);
     if (pl->gexec) (void)hipGraphExecDestroy(pl->gexec);
     delete pl;
 }
@@ -582,6 +589,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         for (hipEvent_t& e : set) HIP_TRY(ctx, hipEventCreate(&e));
     HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_join_copy, hipEventDisableTiming));
     pl->h_chunk_dyn.resize(n_chunks);
     guard.p = nullptr;
     *out = pl;
@@ -599,41 +607,41 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
         HIP_TRY(ctx, hipMemsetAsync(pl->ff_begin, 0xFF, pl->ff_bytes, st));
     HIP_TRY(ctx, hipMemsetAsync(pl->zero_begin, 0, pl->zero_bytes, st));
 
-    // PLAIN fixed-width values: independent of the levels (the reference reads the concatenated
-    // values regions as one stream).  The gather is HBM-bound and the level / string chains are
-    // instruction-bound, so when both exist the gather runs beside them on a second stream.  The first
-    // pass over the strings (exit tables, hops, totals) needs nothing from the levels either and the level
-    // chain of a string column is a few thousand tiles that leave most of the device idle, so it goes to
-    // the second stream too; only the marking pass waits for the value counts.
+    // Three streams.  The PLAIN value gather is independent of the levels (the reference reads the concatenated
+    // values regions as one stream) and HBM-bound, while the level and string kernels are instruction-bound, so
+    // the gather runs beside them on a stream of its own.  The first pass over the strings (exit tables, hops,
+    // totals) needs nothing from the levels either and goes to another side stream; only the strings' marking
+    // pass waits for the value counts.  Levels, page scan, bools and row offsets stay on the main stream.
     const bool str_early = ctx->overlap && n_lreg && n_sreg;
-    const bool side = ctx->overlap && ((pl->n_copy_blocks && (n_lreg || n_sreg)) || str_early);
-    hipStream_t cst = side ? ctx->stream2 : st;
-    if (side) {
-        HIP_TRY(ctx, hipEventRecord(pl->ev_fork, st));
-        HIP_TRY(ctx, hipStreamWaitEvent(cst, pl->ev_fork, 0));
-    }
+    const bool copy_side = ctx->overlap && pl->n_copy_blocks && (n_lreg || n_sreg);
+    hipStream_t cst = copy_side ? ctx->stream3 : st, sst = str_early ? ctx->stream2 : st;
+    if (copy_side || str_early) HIP_TRY(ctx, hipEventRecord(pl->ev_fork, st));
+    if (copy_side) HIP_TRY(ctx, hipStreamWaitEvent(cst, pl->ev_fork, 0));
     if (ev_c0) HIP_TRY(ctx, hipEventRecord(ev_c0, cst));
     HIP_TRY(ctx, launch_copy(cst, src, pl->d_segs, pl->d_seg_blk_prefix, (u32)pl->segs.size(), pl->n_copy_blocks, ctx->copy_grid));
     if (ev_c1) HIP_TRY(ctx, hipEventRecord(ev_c1, cst));
-    if (str_early)
-        HIP_TRY(ctx, launch_chain(cst, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 0));
-    if (side) HIP_TRY(ctx, hipEventRecord(pl->ev_join, cst));
+    if (copy_side) HIP_TRY(ctx, hipEventRecord(pl->ev_join_copy, cst));
+    if (str_early) {
+        HIP_TRY(ctx, hipStreamWaitEvent(sst, pl->ev_fork, 0));
+        HIP_TRY(ctx, launch_chain(sst, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 0));
+        HIP_TRY(ctx, hipEventRecord(pl->ev_join, sst));
+    }
 
-    // levels
+    // levels, then everything that only needs them
     if (n_lreg) HIP_TRY(ctx, launch_levels(st, src, pl->lv));
     HIP_TRY(ctx, launch_page_scan(st, pl->d_chunks, n_chunks, pl->d_pages, n_pages, pl->d_page_dyn, pl->d_chunk_dyn, pl->d_status));
     HIP_TRY(ctx, launch_value_index(st, pl->d_chunks, pl->d_pages, pl->d_page_dyn, pl->d_vidx_pages, (u32)pl->vidx_pages.size(), pl->d_lvl_off));
     HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, (u32)pl->bool_pages.size(), pl->n_btiles,
                               pl->d_chunks, pl->d_page_dyn, pl->d_status));
+    HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
+                             pl->d_row_tiles, pl->d_chunk_dyn));
     if (n_sreg) {
         if (str_early) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join, 0));
         else HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 0));
         HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 1));
         HIP_TRY(ctx, launch_str_check(st, pl->d_pages, pl->d_chunks, pl->d_page_dyn, pl->d_sregions, n_sreg, pl->d_stotals, pl->d_status));
     }
-    HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
-                             pl->d_row_tiles, pl->d_chunk_dyn));
-    if (side) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join, 0));
+    if (copy_side) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join_copy, 0));
     return PQD_OK;
 }
 
