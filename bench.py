@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--pages", type=int, default=None, help="pages per column chunk (default 1 for mixed, 64 for flat, 8 otherwise)")
     ap.add_argument("--row-groups", type=int, default=None, help="row groups per GPU (default 96 for mixed, 4 for flat, 2 otherwise)")
     ap.add_argument("--rows-per-page", type=int, default=1_000_000)
-    ap.add_argument("--workload", default="mixed", choices=["mixed", "flat", "optional", "optint", "optstr", "nested"])
+    ap.add_argument("--workload", default="mixed", choices=["mixed", "flat", "optional", "optint", "optstr", "nested", "bools"])
     ap.add_argument("--no-extras", action="store_true", help="skip the per-workload lines measured beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="per CPU baseline leg (one thread, all cores)")
@@ -85,6 +85,10 @@ def _optional_cols(N, Column):
     return [Column("oi32", N.INT32, [1]), Column("ostr", N.BYTE_ARRAY, [1])]
 
 
+def _bool_cols(N, Column):
+    return [Column("b", N.BOOLEAN, [0]), Column("ob", N.BOOLEAN, [1])]
+
+
 def _person_cols(N, Column):
     # README.md:146-159 Person{Being{ID int32; Age *int32}; Username string; Friends []Being}
     return [Column("being.id", N.INT32, [0, 0]), Column("being.age", N.INT32, [0, 1]), Column("username", N.BYTE_ARRAY, [0]),
@@ -99,6 +103,11 @@ def _gen_page(N, name, rng, n):
         return rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64), None, None, None
     if name == "f64":
         return rng.random(n), None, None, None
+    if name == "b":
+        return rng.integers(0, 2, n, dtype=np.uint8), None, None, None
+    if name == "ob":
+        mask = rng.random(n) >= 0.1
+        return rng.integers(0, 2, int(mask.sum()), dtype=np.uint8), mask.astype(np.uint8), None, None
     if name == "oi32":
         mask = rng.random(n) >= 0.1
         return rng.integers(-2**31, 2**31 - 1, int(mask.sum()), dtype=np.int64).astype(np.int32), mask.astype(np.uint8), None, None
@@ -141,10 +150,10 @@ def build_file(workload, rg_ids, pages, rows_per_page):
     from parquet_amd import _native as N
     from parquet_amd.writer import Column, ParquetWriter
     cols = {"flat": _flat_cols(N, Column), "optional": _optional_cols(N, Column), "optint": _optional_cols(N, Column)[:1],
-            "optstr": _optional_cols(N, Column)[1:],
+            "optstr": _optional_cols(N, Column)[1:], "bools": _bool_cols(N, Column),
             "nested": [c for c in _person_cols(N, Column) if c.path != "username"],
             "mixed": _flat_cols(N, Column) + _optional_cols(N, Column) + _person_cols(N, Column)}[workload]
-    seed0 = {"flat": 1000, "optional": 2000, "optint": 2000, "optstr": 2000, "nested": 3000, "mixed": 5000}[workload]
+    seed0 = {"flat": 1000, "optional": 2000, "optint": 2000, "optstr": 2000, "nested": 3000, "mixed": 5000, "bools": 6000}[workload]
     w = ParquetWriter(cols, stats=True)
     w.reserve(len(rg_ids) * pages * rows_per_page * sum(30 if c.phys_type == N.BYTE_ARRAY else 10 for c in cols) + (1 << 20))
     ex = Expect()
@@ -234,6 +243,7 @@ def cpu_baseline(buf, pf, seconds, threads):
 DOMINANT = {"flat": "k_copy (PLAIN value gather)", "optint": "k_levels (single-pass level decode) beside k_copy",
             "optional": "k_str_exits / k_str_mark (BYTE_ARRAY chain)", "optstr": "k_str_exits / k_str_mark (BYTE_ARRAY chain)",
             "nested": "k_levels (single-pass level decode) and k_rows (row offsets)",
+            "bools": "k_bools (bit -> byte expansion) and k_levels",
             "mixed": "k_str_exits / k_str_mark (BYTE_ARRAY chain), k_levels and k_copy on two streams"}
 DESCRIBE = {
     "mixed": "this GPU's share of configs[4]: configs[1]+[2]+[3] columns side by side (flat int32/int64/float64, optional int32 + string with "
@@ -242,9 +252,10 @@ DESCRIBE = {
     "optional": "configs[2]: optional int32 + string columns, 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
     "nested": "configs[3]: Person{Being,Friends []Being} int32 leaves, %d rows/page, %d pages/chunk, %d row groups per GPU",
     "optint": "configs[2], int32 half: optional int32 column, 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
+    "bools": "required + optional (10%% nulls) bool columns, %d rows/page, %d pages/chunk, %d row groups per GPU",
     "optstr": "configs[2], string half: optional string column (8-32 B), 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
 }
-DEFAULT_SHAPE = {"mixed": (1, 96), "flat": (64, 4), "optional": (8, 2), "optint": (8, 2), "optstr": (8, 2), "nested": (8, 2)}  # pages, row groups
+DEFAULT_SHAPE = {"mixed": (1, 96), "flat": (64, 4), "optional": (8, 2), "optint": (8, 2), "optstr": (8, 2), "nested": (8, 2), "bools": (32, 2)}  # pages, row groups
 
 
 class Loaded:

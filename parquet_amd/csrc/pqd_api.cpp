@@ -449,8 +449,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_rtp = ap.take(pl->rtile_prefix.size() * 4);
     // scratch
     const size_t o_sexit = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * sizeof(StrExit));
-    const size_t o_scp = ap.take((size_t)pl->n_stiles_chain * CH_THREADS * 16);
-    const size_t o_smap = ap.take((size_t)pl->n_stiles_chain * (CH_T / 8) * 2);
+    const size_t o_scp = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * 16);
     const size_t o_scand = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * 2);
     const size_t o_sncand = ap.take((size_t)pl->n_stiles_chain * 2), o_sgpre = ap.take((size_t)pl->n_stiles_chain * 2);
     const size_t o_sspre = ap.take((size_t)pl->n_stiles_chain * 2);
@@ -562,7 +561,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                            n_sgroups, pl->d_sexit, pl->d_sgexit, pl->d_stile_entry, pl->d_sgroup_entry, pl->d_stotals, A + o_scp,
                            (u32*)(A + o_ssp), n_ssupers, (ExitRec*)(A + o_ssexit), (TileEntry*)(A + o_sse)};
     pl->schain.tile_region = (u32*)(A + o_str);
-    pl->schain.str_index = StrIndex{(const unsigned short*)(A + o_smap), (const unsigned short*)(A + o_scand),
+    pl->schain.str_index = StrIndex{(const unsigned short*)(A + o_scand),
                                     (const unsigned short*)(A + o_sncand), (unsigned short*)(A + o_sgpre), (unsigned short*)(A + o_sspre)};
 
     int rc;

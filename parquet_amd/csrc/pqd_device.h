@@ -39,7 +39,7 @@ constexpr u32 CH_T = CH_THREADS * CH_SUB;  // source bytes per tile (2048)
 constexpr u32 CH_WIN = CH_SUB / 4 + 2;    // dwords a lane holds: its sub-tile + 8 bytes of lookahead
 constexpr u32 CH_E_LEVELS = 256;  // tabulated entry positions per tile: covers the reference writer's longest
                                   // run (1 + 63 groups x 4 bytes); longer jumps take the serial hop
-constexpr u32 CH_E_STRINGS = 64;  // rows per tile: its first 64 plausible string starts (see StrIndex)
+constexpr u32 CH_E_STRINGS = 8;   // rows per tile: its first plausible string starts (see StrIndex)
 
 constexpr u32 CH_SERIAL = 32;     // level tiles with at most this many runs are marked by a serial walk
 constexpr u32 CH_G_LEVELS = 8;    // tiles per hop group (level blocks are ~60 tiles per 1M-value page)
@@ -110,9 +110,8 @@ hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32
                        u32 max_grid);
 // strings: which positions of a chain tile are plausible string starts (see entry_slot in pqd_kernels.hip)
 struct StrIndex {
-    const unsigned short* map;   // n_tiles * 256 words: plausibility bits of 8 positions | plausible positions before them << 8
-    const unsigned short* cand;  // n_tiles * 64: tile offsets of the first 64 plausible positions, 0xFFFF = none
-    const unsigned short* ncand; // n_tiles: plausible positions of the tile (counted until its 64 rows were full)
+    const unsigned short* cand;  // n_tiles * CH_E_STRINGS: tile offsets of the first plausible positions, ascending, 0xFFFF = none
+    const unsigned short* ncand; // n_tiles: plausible positions of the tile (counted until its rows were full)
     unsigned short* gpre;        // n_tiles: plausible positions in the earlier tiles of the tile's group (k_chain_groups)
     unsigned short* spre;        // n_tiles: ... of the tile's super-group (k_chain_supers)
 };
@@ -126,7 +125,7 @@ struct ChainArgs {
     TileEntry* tile_entry;    // n_tiles   (reset to 0xFF before every run)
     TileEntry* group_entry;   // n_groups  (reset to 0xFF before every run)
     RegionTotal* totals;      // n_regions
-    void* str_cp;             // strings: n_tiles * 64 rows of 8 u16 walk checkpoints (1 KiB per tile)
+    void* str_cp;             // strings: n_tiles * CH_E_STRINGS rows of 8 u16 walk checkpoints
     const u32* super_prefix;  // n_regions + 1; super-groups are optional (n_supers == 0: three levels)
     u32 n_supers;
     ExitRec* sexit;           // n_supers * E

@@ -527,83 +527,76 @@ static __device__ __forceinline__ u32 str_len_at(const u32* s_tile, u32 rel) {
     return __builtin_amdgcn_alignbit(s_tile[d + 1], s_tile[d], (rel & 3) * 8);
 }
 
-// The row of a tile's exit table that belongs to tile offset off, from the map entry of off's 8 positions
-// (plausibility bits | plausible positions in front of them << 8); NO_SLOT when off is not among the first 64.
-static __device__ __forceinline__ u32 str_row(u32 word, u32 off) {  // word = the map entry of off's 8 positions
-    const u32 m = word & 0xFF, b = off & 7;
-    if (!((m >> b) & 1)) return NO_SLOT;
-    const u32 slot = (word >> 8) + __popc(m & ((1u << b) - 1));
-    return slot < CH_E_STRINGS ? slot : NO_SLOT;
-}
-
-// Pass 1, STR_TG tiles per wave.
+// Pass 1: STR_A tiles per wave, CH_E_STRINGS rows per tile.
 //   candidates  the positions of a tile whose four bytes are a length that fits in the page.  Every true string
-//               start is one; in text hardly anything else is.  The tile's exit table rows are its first 64
-//               candidates in position order, whatever their distance from the tile start: long strings enter a
-//               tile anywhere.  The plausibility bits of all positions and their running count go to str_map,
-//               which turns a position into its row (entry_slot), the positions of the rows to str_cand.
-//   one step    every row's candidate takes one step.  It leaves the tile (done), lands on another row's
-//               candidate (a link: from there on the two chains are one), or lands further on in the tile:
-//               only those few chains are walked to the end, packed into a queue so that the walks of all
-//               tiles share the lanes of the wave.
-//   links       pointer jumping over the 64 rows of every tile folds exits, string counts and checkpoints (the
-//               first position of the chain inside each 256-byte block, for pass 2) along the links.
-// Text tiles have at most one or two chains to walk (the true chain beyond its 64th candidate); tiles of
-// strings longer than ~30 bytes have none.
-constexpr u32 STR_TG = 4;
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-static __device__ __forceinline__ u32 min_u16x2(u32 a, u32 b) {
-    const u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
-    return __builtin_bit_cast(u32, r);
-}
+//               start is one; in text hardly anything else is (the two positions in front of a true start, whose
+//               bytes end in the zero bytes of its length).  The rows of a tile's exit table are its first
+//               CH_E_STRINGS candidates in position order, whatever their distance from the tile start: long strings
+//               enter a tile anywhere, and the first true start of the tile has only the candidates in front of it
+//               that the tail of the entering string holds.  Their positions go to str_cand (entry_slot looks a
+//               position up there).  The first STR_PROBE positions of four tiles are searched at once, 16 lanes per
+//               tile; only tiles that have fewer rows than that (long strings) are searched further, 512 positions
+//               of one tile at a time.
+//   one step    every row's candidate takes one step.  Most rows are done with it: the two positions in front of a
+//               true start jump far (their length has the true length in a high byte) or die.
+//   walks       the others, packed into the lanes of the wave whatever their tile, walk their chain to the end of
+//               the tile through the LDS image: strings started on the way, where the chain leaves the tile (or
+//               ERR_POS: a length that does not fit), and, for pass 2, the chain's first position in every
+//               256-byte block after the row's own.  Rows of one tile that lie on the same chain repeat each
+//               other's steps, which costs nothing: all walks of the wave are one loop.
+constexpr u32 STR_A = 8;        // tiles per wave
+constexpr u32 STR_PROBE = 128;
+constexpr u32 STR_PAIRS = STR_A * CH_E_STRINGS;  // (tile, row) pairs of a wave
+static_assert(STR_A % 4 == 0, "the probe takes four tiles at a time");
+static_assert(STR_PAIRS % CH_THREADS == 0 && STR_PAIRS <= 256, "whole passes of one lane per pair; a pair index fits in 8 bits");
+static_assert(CH_E_STRINGS % 8 == 0, "a tile's candidate row is read in 16-byte pieces");
 __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                           const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
                                                           ExitRec* __restrict__ exit_tbl, u32x4* __restrict__ str_cp,
-                                                          const u32* __restrict__ tile_region, unsigned short* __restrict__ str_map,
+                                                          const u32* __restrict__ tile_region,
                                                           unsigned short* __restrict__ str_cand, unsigned short* __restrict__ str_ncand) {
-    static_assert(CH_E_STRINGS == CH_THREADS, "one lane per row of a tile's exit table");
-    static_assert(STR_TG <= 8, "queue entry: 3 bits tile, offset above");
     static_assert(STR_CP == 8, "a checkpoint row is 8 x u16");
-    constexpr u32 NO_LINK = 0xFF;
-    __shared__ __attribute__((aligned(16))) u32 s_tile[STR_TG * STR_LDS_WORDS];
-    // first the plausibility words of the tiles (row lookup of the one-step landings), later the checkpoint
-    // rows of the walked chains (32-bit slots for the LDS atomic)
-    __shared__ __attribute__((aligned(16))) u64 s_mapcp[STR_TG * (CH_T / 32) > CH_THREADS * STR_CP / 2 ? STR_TG * (CH_T / 32) : CH_THREADS * STR_CP / 2];
-    static_assert(sizeof(s_mapcp) >= STR_TG * (CH_T / 8) * 2 && sizeof(s_mapcp) >= CH_THREADS * STR_CP * 4, "map words, then checkpoint rows");
-    __shared__ u32 s_queue[STR_TG * CH_THREADS];
-    __shared__ u32 s_tb[STR_TG], s_len[STR_TG];
-    __shared__ u64 s_src[STR_TG];
-    __shared__ unsigned short s_cand[STR_TG][CH_E_STRINGS];
-    const u32 lane = threadIdx.x, t0 = blockIdx.x * STR_TG;
-    const u32 nt = n_tiles - t0 < STR_TG ? n_tiles - t0 : STR_TG;
+    constexpr u32 E = CH_E_STRINGS, A = STR_A;
+    __shared__ __attribute__((aligned(16))) u32 s_tile[A * STR_LDS_WORDS];
+    __shared__ u32 s_tb[A], s_len[A], s_found[A];
+    __shared__ u64 s_src[A];
+    __shared__ unsigned short s_cand[A][E];
+    __shared__ __attribute__((aligned(16))) u32 s_cp[STR_PAIRS][STR_CP];  // 32-bit slots for the LDS atomic
+    __shared__ u32 s_exit[STR_PAIRS], s_queue[STR_PAIRS];
+    __shared__ unsigned short s_cnt[STR_PAIRS];
+    const u32 lane = threadIdx.x, t0 = blockIdx.x * A;
+    const u32 nt = n_tiles - t0 < A ? n_tiles - t0 : A;
 #pragma unroll
-    for (u32 t = 0; t < STR_TG; t++) s_cand[t][lane] = 0xFFFF;
-    if (lane < nt) {
-        const u32 ri = tile_region ? tile_region[t0 + lane] : find_owner(tile_prefix, n_regions, t0 + lane);
-        const Region R = regions[ri];
-        s_tb[lane] = (t0 + lane - tile_prefix[ri]) * CH_T;
-        s_len[lane] = R.len;
-        s_src[lane] = R.src_off;
+    for (u32 i = lane; i < STR_PAIRS; i += CH_THREADS) s_cand[i / E][i % E] = 0xFFFF;
+    if (lane < A) {
+        u32 tb = 0, len = 0;
+        u64 so = 0;
+        if (lane < nt) {
+            const u32 ri = tile_region ? tile_region[t0 + lane] : find_owner(tile_prefix, n_regions, t0 + lane);
+            const Region R = regions[ri];
+            tb = (t0 + lane - tile_prefix[ri]) * CH_T; len = R.len; so = R.src_off;
+        }
+        s_tb[lane] = tb; s_len[lane] = len; s_src[lane] = so; s_found[lane] = 0;  // absent tiles: length 0, nothing is plausible
     }
     __syncthreads();
-    bool whole = nt == STR_TG;  // every tile complete, lookahead included: all loads can be in flight at once
+    bool whole = nt == A;  // every tile complete, lookahead included: all loads can be in flight at once
     for (u32 t = 0; t < nt; t++) whole = whole && s_tb[t] + CH_T + 4 <= s_len[t];
     if (whole) {
-        u32x4 a[STR_TG], b[STR_TG];
+        u32x4 a[A], b[A];
 #pragma unroll
-        for (u32 t = 0; t < STR_TG; t++) {
+        for (u32 t = 0; t < A; t++) {
             const u8* p = src_base + s_src[t] + s_tb[t] + lane * CH_SUB;
             a[t] = *(const u32x4_u*)p;
             b[t] = *(const u32x4_u*)(p + 16);
         }
         u32 ahead = 0;
-        if (lane < STR_TG) ahead = *(const u32_u*)(src_base + s_src[lane] + s_tb[lane] + CH_T);
+        if (lane < A) ahead = *(const u32_u*)(src_base + s_src[lane] + s_tb[lane] + CH_T);
 #pragma unroll
-        for (u32 t = 0; t < STR_TG; t++) {
+        for (u32 t = 0; t < A; t++) {
             *(u32x4*)(s_tile + t * STR_LDS_WORDS + lane * 8) = a[t];
             *(u32x4*)(s_tile + t * STR_LDS_WORDS + lane * 8 + 4) = b[t];
         }
-        if (lane < STR_TG) { s_tile[lane * STR_LDS_WORDS + CH_T / 4] = ahead; s_tile[lane * STR_LDS_WORDS + CH_T / 4 + 1] = 0; }
+        if (lane < A) { s_tile[lane * STR_LDS_WORDS + CH_T / 4] = ahead; s_tile[lane * STR_LDS_WORDS + CH_T / 4 + 1] = 0; }
     } else {
         for (u32 t = 0; t < nt; t++) {
             u32 w[8];
@@ -611,160 +604,141 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
         }
     }
     __syncthreads();
-    const u64 lt = (1ull << lane) - 1;
-    u32 tbs[STR_TG], lens[STR_TG], lims[STR_TG];
+    // ---- candidates; a position p is one when len < max(L - 3 - p, 0), which is what str_step_win accepts (and is
+    // false for p >= L).  First the leading STR_PROBE positions of four tiles at a time, 8 positions per lane.
 #pragma unroll
-    for (u32 t = 0; t < STR_TG; t++) {
-        tbs[t] = t < nt ? s_tb[t] : 0;
-        lens[t] = t < nt ? s_len[t] : 0;
-        lims[t] = tbs[t] + CH_T < lens[t] ? tbs[t] + CH_T : lens[t];
+    for (u32 it = 0; it < A / 4; it++) {
+        const u32 t = it * 4 + (lane >> 4), j = lane & 15, o = j * 8;
+        const u32* tl = s_tile + t * STR_LDS_WORDS + o / 4;
+        const u32 x[3] = {tl[0], tl[1], tl[2]};
+        const int room = (int)(s_len[t] - 3 - s_tb[t] - o);  // L - 3 - p for my first position
+        u32 m = 0;
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) {
+            const u32 len = (k & 3) ? __builtin_amdgcn_alignbit(x[k / 4 + 1], x[k / 4], (k & 3) * 8) : x[k / 4];
+            const int r = room - (int)k;
+            m |= (u32)(len < (u32)(r > 0 ? r : 0)) << k;
+        }
+        const u32 mine = __popc(m);
+        u32 incl = mine;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const u32 y = __shfl_up(incl, d);
+            if (j >= (u32)d) incl += y;
+        }
+        u32 slot = incl - mine;
+        const u32 total = __shfl(incl, lane | 15);
+        while (m && slot < E) {
+            const u32 k = __ffs(m) - 1;
+            m &= m - 1;
+            s_cand[t][slot++] = (unsigned short)(o + k);
+        }
+        if (j == 0) s_found[t] = total;
     }
-    // ---- candidates, 512 positions (8 per lane) at a time until the tile has its 64 rows; a position p is one
-    // when len < max(L - 3 - p, 0), which is what str_step_win accepts (and is false for p >= L)
-    unsigned short* const s_map = (unsigned short*)s_mapcp;
-#pragma unroll
-    for (u32 t = 0; t < STR_TG; t++) {
-        if (t >= nt) break;
-        u32 found = 0;
-        for (u32 c = 0; c < CH_T / 512; c++) {
-            u32 m = 0, pre = 255;
-            if (found < CH_E_STRINGS) {  // uniform
-                const u32 o = c * 512 + lane * 8;
+    __syncthreads();
+    // tiles whose leading positions hold fewer candidates than rows: the rest of the tile, 512 positions at a time
+    for (u32 t = 0; t < nt; t++) {
+        const u32 tb = s_tb[t], L = s_len[t];
+        const u32 rlim = tb + CH_T < L ? CH_T : L - tb;
+        u32 found = s_found[t];
+        if (found >= E || rlim <= STR_PROBE) continue;  // uniform
+        for (u32 c0 = STR_PROBE; c0 < rlim && found < E; c0 += 512) {
+            const u32 o = c0 + lane * 8;
+            u32 m = 0;
+            if (o < CH_T) {
                 const u32* tl = s_tile + t * STR_LDS_WORDS + o / 4;
                 const u32 x[3] = {tl[0], tl[1], tl[2]};
-                const int room = (int)(lens[t] - 3 - tbs[t] - o);  // L - 3 - p for my first position
+                const int room = (int)(L - 3 - tb - o);
 #pragma unroll
                 for (u32 k = 0; k < 8; k++) {
                     const u32 len = (k & 3) ? __builtin_amdgcn_alignbit(x[k / 4 + 1], x[k / 4], (k & 3) * 8) : x[k / 4];
                     const int r = room - (int)k;
                     m |= (u32)(len < (u32)(r > 0 ? r : 0)) << k;
                 }
-                const u32 mine = __popc(m);
-                u32 incl = mine;
-                for (int d = 1; d < 64; d <<= 1) {
-                    const u32 y = __shfl_up(incl, d);
-                    if (lane >= (u32)d) incl += y;
-                }
-                u32 slot = found + incl - mine;
-                pre = slot < 255 ? slot : 255;
-                found += __shfl(incl, 63);
-                u32 mm = m;
-                while (mm && slot < CH_E_STRINGS) {
-                    const u32 k = __ffs(mm) - 1;
-                    mm &= mm - 1;
-                    s_cand[t][slot++] = (unsigned short)(o + k);
-                }
             }
-            const unsigned short word = (unsigned short)(m | (pre << 8));
-            str_map[(u64)(t0 + t) * (CH_T / 8) + c * 64 + lane] = word;
-            s_map[t * (CH_T / 8) + c * 64 + lane] = word;
+            const u32 mine = __popc(m);
+            u32 incl = mine;
+            for (int d = 1; d < 64; d <<= 1) {
+                const u32 y = __shfl_up(incl, d);
+                if (lane >= (u32)d) incl += y;
+            }
+            u32 slot = found + incl - mine;
+            found += __shfl(incl, 63);
+            while (m && slot < E) {
+                const u32 k = __ffs(m) - 1;
+                m &= m - 1;
+                s_cand[t][slot++] = (unsigned short)(o + k);
+            }
         }
-        if (lane == 0) str_ncand[t0 + t] = (unsigned short)found;  // counted until the table was full
+        if (lane == 0) s_found[t] = found;
     }
     __syncthreads();
-    // ---- one step per row; lane = row.  Per row and tile, in registers: where the chain leaves the tile,
-    // strings passed | link << 16, checkpoints (8 x u16)
-    u32 tg[STR_TG], cl[STR_TG], myq[STR_TG];
-    u32x4 rw[STR_TG];
+    // ---- one step per row, one lane per (tile, row) pair; the chains that stay inside their tile are queued
+    const u64 lt = (1ull << lane) - 1;
+    const u32x4 none = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     u32 qn = 0;
 #pragma unroll
-    for (u32 t = 0; t < STR_TG; t++) {
-        tg[t] = ERR_POS; cl[t] = NO_LINK << 16; myq[t] = 0xFFFFFFFFu;
-        rw[t] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (t >= nt) continue;
-        const u32 c = s_cand[t][lane];
-        str_cand[(u64)(t0 + t) * CH_E_STRINGS + lane] = (unsigned short)c;
-        const bool have = c != 0xFFFF;
-        u32 nxt = ERR_POS;
-        if (have) str_step_win(str_len_at(s_tile + t * STR_LDS_WORDS, c), tbs[t] + c, lens[t], nxt);
-        const bool inside = nxt < lims[t];  // ERR_POS is not
-        const u32 rel = inside ? nxt - tbs[t] : 0;
-        const u32 row = str_row(s_map[t * (CH_T / 8) + (rel >> 3)], rel);
-        const bool linked = inside && row != NO_SLOT;
-        const bool walk = inside && !linked;
-        tg[t] = nxt;
-        cl[t] = (have ? 1u : 0u) | ((linked ? row : NO_LINK) << 16);
-        // the landing is the first position of my chain in its block
-        if (inside) {
-            const u32 k = rel / STR_CP_BYTES;
-            const u32 v = (k & 1) ? (0xFFFFu | (rel << 16)) : (0xFFFF0000u | rel);
-            if ((k >> 1) == 0) rw[t].x = v;
-            if ((k >> 1) == 1) rw[t].y = v;
-            if ((k >> 1) == 2) rw[t].z = v;
-            if ((k >> 1) == 3) rw[t].w = v;
+    for (u32 i0 = 0; i0 < STR_PAIRS; i0 += CH_THREADS) {
+        const u32 i = i0 + lane, t = i / E;
+        const u32 tb = s_tb[t], L = s_len[t];
+        const u32 rlim = t < nt ? (tb + CH_T < L ? CH_T : L - tb) : 0;
+        const u32 c0 = s_cand[t][i % E];
+        *(u32x4*)s_cp[i] = none;
+        *(u32x4*)(s_cp[i] + 4) = none;
+        u32 rel = ERR_POS, cnt = 0;
+        if (c0 != 0xFFFF) {  // a candidate is plausible, so its step succeeds
+            rel = c0 + 4 + str_len_at(s_tile + t * STR_LDS_WORDS, c0);
+            cnt = 1;
         }
+        const bool walk = rel < rlim;
+        s_exit[i] = rel == ERR_POS ? ERR_POS : tb + rel;
+        s_cnt[i] = (unsigned short)cnt;
         const u64 bal = __ballot(walk);
-        if (walk) {
-            myq[t] = qn + (u32)__popcll(bal & lt);
-            s_queue[myq[t]] = t | (rel << 3);
-        }
+        if (walk) s_queue[qn + (u32)__popcll(bal & lt)] = i | (rel << 8);
         qn += (u32)__popcll(bal);
     }
     __syncthreads();
-    // ---- the chains that neither left their tile nor met another row: walked to the end, 64 at a time, and
-    // handed back to the lanes of their rows
-    u32* const s_cp = (u32*)s_mapcp;
-    const u32x4 none = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // ---- walks, 64 chains at a time
     for (u32 base = 0; base < qn; base += CH_THREADS) {
         const bool have = base + lane < qn;
         const u32 e = have ? s_queue[base + lane] : 0;
-        const u32 t = e & 7;
+        const u32 i = e & 0xFF, t = i / E;
         const u32 tb = s_tb[t], L = s_len[t];
-        const u32 lim = tb + CH_T < L ? tb + CH_T : L;
+        const u32 rlim = tb + CH_T < L ? CH_T : L - tb;
+        // a position needs its four length bytes inside the region: up to there the room is positive and
+        // a length is accepted when len < room = L - 3 - position
+        const u32 avail = L - tb, room0 = avail - 3, rlim4 = avail < 4 ? 0 : rlim < room0 ? rlim : room0;
         const u32* tl = s_tile + t * STR_LDS_WORDS;
-        u32* cp = s_cp + lane * STR_CP;
-        *(u32x4*)cp = none;
-        *(u32x4*)(cp + 4) = none;
-        // the walk in tile offsets: a length is accepted when len < max(L - 3 - position, 0)
-        const u32 rlim = lim - tb;
-        const int room0 = (int)(L - 3 - tb);
-        u32 rel = have ? e >> 3 : ERR_POS, c = 1;
-        while (rel < rlim) {  // ERR_POS ends the loop too
-            atomicMin(cp + rel / STR_CP_BYTES, rel);  // positions only grow: the first one of every block stays
-            const u32 len = str_len_at(tl, rel);
-            const int room = room0 - (int)rel;
-            rel = len < (u32)(room > 0 ? room : 0) ? rel + 4 + len : ERR_POS;
-            c++;
+        u32* cp = s_cp[i];
+        u32 rel = have ? e >> 8 : ERR_POS, cnt = 1, pb = 0xFFFFFFFFu;
+        while (rel < rlim4) {  // ERR_POS ends the loop too
+            const u32 nb = rel / STR_CP_BYTES;
+            if (nb != pb) cp[nb] = rel;  // positions only grow: the first one of every block
+            pb = nb;
+            const u32 len = str_len_at(tl, rel);  // two aligned words: an unaligned LDS read is slower
+            rel = len < room0 - rel ? rel + 4 + len : ERR_POS;
+            cnt++;
         }
-        const u32 qq = rel == ERR_POS ? ERR_POS : tb + rel;
-        const u32x4 lo = *(const u32x4*)cp, hi = *(const u32x4*)(cp + 4);  // own row: no barrier needed
-        const u32x4 wr = u32x4{(lo.x & 0xFFFFu) | (lo.y << 16), (lo.z & 0xFFFFu) | (lo.w << 16),
-                               (hi.x & 0xFFFFu) | (hi.y << 16), (hi.z & 0xFFFFu) | (hi.w << 16)};
-#pragma unroll
-        for (u32 k = 0; k < STR_TG; k++) {
-            const bool mine = myq[k] != 0xFFFFFFFFu && myq[k] - base < CH_THREADS;  // walked in this batch
-            const u32 from = mine ? myq[k] - base : lane;
-            const u32 g_t = __shfl(qq, from), g_c = __shfl(c, from);
-            const u32 g_x = __shfl(wr.x, from), g_y = __shfl(wr.y, from), g_z = __shfl(wr.z, from), g_w = __shfl(wr.w, from);
-            if (mine) { tg[k] = g_t; cl[k] = g_c | (NO_LINK << 16); rw[k] = u32x4{g_x, g_y, g_z, g_w}; }
+        if (rel < rlim) { rel = ERR_POS; cnt++; }  // a start in the last three bytes of the region
+        if (have) {
+            s_exit[i] = rel == ERR_POS ? ERR_POS : tb + rel;
+            s_cnt[i] = (unsigned short)cnt;
         }
     }
-    // ---- links: a row's link points to a later row, so 6 rounds of pointer jumping reach the end of every list
-    for (u32 round = 0; round < 6; round++) {
-        bool any = false;
+    __syncthreads();
 #pragma unroll
-        for (u32 t = 0; t < STR_TG; t++) any = any || (cl[t] >> 16) != NO_LINK;
-        if (!__any(any)) break;
-#pragma unroll
-        for (u32 t = 0; t < STR_TG; t++) {
-            const bool linked = (cl[t] >> 16) != NO_LINK;
-            const u32 j = linked ? cl[t] >> 16 : lane;
-            const u32 tj = __shfl(tg[t], j), cj = __shfl(cl[t], j);
-            const u32 xj = __shfl(rw[t].x, j), yj = __shfl(rw[t].y, j), zj = __shfl(rw[t].z, j), wj = __shfl(rw[t].w, j);
-            if (linked) {
-                tg[t] = tj;
-                cl[t] = ((cl[t] & 0xFFFF) + (cj & 0xFFFF)) | (cj & 0xFFFF0000u);
-                rw[t] = u32x4{min_u16x2(rw[t].x, xj), min_u16x2(rw[t].y, yj), min_u16x2(rw[t].z, zj), min_u16x2(rw[t].w, wj)};
-            }
-        }
-    }
-#pragma unroll
-    for (u32 t = 0; t < STR_TG; t++) {
-        if (t >= nt) break;
+    for (u32 i0 = 0; i0 < STR_PAIRS; i0 += CH_THREADS) {
+        const u32 i = i0 + lane, t = i / E;
+        if (t >= nt) continue;
         StrExit x;
-        x.tgt = tg[t]; x.cnt = cl[t] & 0xFFFF;
-        ((StrExit*)exit_tbl)[(u64)(t0 + t) * CH_E_STRINGS + lane] = x;
-        str_cp[(u64)(t0 + t) * CH_THREADS + lane] = rw[t];
+        x.tgt = s_exit[i];
+        x.cnt = s_cnt[i];
+        ((StrExit*)exit_tbl)[(u64)t0 * E + i] = x;
+        const u32x4 lo = *(const u32x4*)s_cp[i], hi = *(const u32x4*)(s_cp[i] + 4);
+        str_cp[(u64)t0 * E + i] = u32x4{(lo.x & 0xFFFFu) | (lo.y << 16), (lo.z & 0xFFFFu) | (lo.w << 16),
+                                        (hi.x & 0xFFFFu) | (hi.y << 16), (hi.z & 0xFFFFu) | (hi.w << 16)};
+        str_cand[(u64)t0 * E + i] = s_cand[t][i % E];
+        if (i % E == 0) { const u32 f = s_found[t]; str_ncand[t0 + t] = (unsigned short)(f < 0xFFFF ? f : 0xFFFF); }
     }
 }
 
@@ -809,7 +783,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
         if (wt == t && on[t]) { w_epos = epos[t]; w_tile = t0 + t; w_slot = eslot[t]; }
     const u32 w_b0 = (w_epos & (CH_T - 1)) / STR_CP_BYTES;  // the entry's block; tiles start at multiples of CH_T of the region
     unsigned short cp = 0xFFFF;
-    if (w_epos != ERR_POS && w_slot != NO_SLOT) cp = ((const unsigned short*)(str_cp + (u64)w_tile * CH_THREADS + w_slot))[wj];
+    if (w_epos != ERR_POS && w_slot != NO_SLOT) cp = ((const unsigned short*)(str_cp + (u64)w_tile * CH_E_STRINGS + w_slot))[wj];
     Region R[STR_MG];
     PageDyn pd[STR_MG];
     u32 tb[STR_MG], lim[STR_MG];
@@ -962,9 +936,21 @@ static __device__ __forceinline__ u32 entry_slot(const StrIndex& sx, u32 first, 
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     if (KIND != KIND_STRINGS) return off < E ? (u32)off : NO_SLOT;
     const u32 tile = first + (u32)(off / CH_T), o = (u32)(off % CH_T);
-    const u32 word = sx.map[(u64)tile * (CH_T / 8) + (o >> 3)];
-    const u32 pre = LEVEL == 0 ? 0 : LEVEL == 1 ? sx.gpre[tile] : sx.spre[tile];  // both loads in flight together
-    const u32 row = str_row(word, o);
+    const u32x4* rows = (const u32x4*)(sx.cand + (u64)tile * E);  // the tile's rows: positions in ascending order, 0xFFFF = none
+    u32x4 c[E / 8];
+#pragma unroll
+    for (u32 q = 0; q < E / 8; q++) c[q] = rows[q];
+    const u32 pre = LEVEL == 0 ? 0 : LEVEL == 1 ? sx.gpre[tile] : sx.spre[tile];  // all loads in flight together
+    u32 row = NO_SLOT;
+#pragma unroll
+    for (u32 q = 0; q < E / 8; q++) {
+        const u32 wds[4] = {c[q].x, c[q].y, c[q].z, c[q].w};
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) {
+            if ((wds[k] & 0xFFFF) == o) row = q * 8 + 2 * k;
+            if ((wds[k] >> 16) == o) row = q * 8 + 2 * k + 1;
+        }
+    }
     if (row == NO_SLOT) return row;
     return row + pre < E ? row + pre : NO_SLOT;
 }
@@ -1066,8 +1052,9 @@ __global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_
                                                      const StrIndex sx) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     constexpr u32 G = chain_group_tiles(KIND);
-    const u32 group = blockIdx.x / (E / 64);
-    const u32 i = (blockIdx.x % (E / 64)) * 64 + threadIdx.x;  // entry row of the group's first tile
+    constexpr u32 BPG = E > 64 ? E / 64 : 1;  // blocks per group: one lane per row, at least one wave
+    const u32 group = blockIdx.x / BPG;
+    const u32 i = (blockIdx.x % BPG) * 64 + threadIdx.x;  // entry row of the group's first tile
     const u32 ri = find_owner(group_prefix, n_regions, group);
     const Region R = regions[ri];
     const u32 L = R.len;
@@ -1085,6 +1072,7 @@ __global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_
         }
         sx.gpre[R.tile_base + t_first + i] = (unsigned short)(acc < 0xFFFF ? acc : 0xFFFF);
     }
+    if (i >= E) return;  // fewer rows than lanes
     u32 p = slot_pos<KIND, 1>(sx, R.tile_base + t_first, g_lo, i, n_scope), cnt = 0;
     u64 vals = 0;
     if (KIND != KIND_STRINGS && p >= g_hi) return;
@@ -1111,8 +1099,9 @@ __global__ __launch_bounds__(64) void k_chain_supers(const u8* __restrict__ src_
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     constexpr u32 G = chain_group_tiles(KIND);
     constexpr u32 GB = G * CH_T;  // bytes per group
-    const u32 sup = blockIdx.x / (E / 64);
-    const u32 i = (blockIdx.x % (E / 64)) * 64 + threadIdx.x;
+    constexpr u32 BPG = E > 64 ? E / 64 : 1;
+    const u32 sup = blockIdx.x / BPG;
+    const u32 i = (blockIdx.x % BPG) * 64 + threadIdx.x;
     const u32 ri = find_owner(super_prefix, n_regions, sup);
     const Region R = regions[ri];
     const u32 L = R.len;
@@ -1141,6 +1130,7 @@ __global__ __launch_bounds__(64) void k_chain_supers(const u8* __restrict__ src_
             }
         }
     }
+    if (i >= E) return;
     u32 p = slot_pos<KIND, 2>(sx, R.tile_base + t_first, s_lo, i, n_scope), cnt = 0;
     u64 vals = 0;
     if (KIND != KIND_STRINGS && p >= s_hi) return;
@@ -2166,22 +2156,22 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
     if (phase == 0) {
         if (a.n_tiles) {
             if constexpr (KIND == KIND_STRINGS)
-                hipLaunchKernelGGL(k_str_exits, dim3((a.n_tiles + STR_TG - 1) / STR_TG), dim3(CH_THREADS), 0, st, src, a.regions,
+                hipLaunchKernelGGL(k_str_exits, dim3((a.n_tiles + STR_A - 1) / STR_A), dim3(CH_THREADS), 0, st, src, a.regions,
                                    a.tile_prefix, a.n_regions, a.n_tiles, a.exit_tbl, (u32x4*)a.str_cp, a.tile_region,
-                                   (unsigned short*)a.str_index.map, (unsigned short*)a.str_index.cand,
+                                   (unsigned short*)a.str_index.cand,
                                    (unsigned short*)a.str_index.ncand);
             else
                 hipLaunchKernelGGL((k_chain<KIND, false, CHAIN_NT>), dim3(a.n_tiles), dim3(CHAIN_NT), 0, st, src, a.regions,
                                    a.tile_prefix, a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn,
                                    a.tile_region);
             LAUNCH_CHECK();
-            hipLaunchKernelGGL((k_chain_groups<KIND>), dim3(a.n_groups * (E / 64)), dim3(64), 0, st, src, a.regions,
+            hipLaunchKernelGGL((k_chain_groups<KIND>), dim3(a.n_groups * (E > 64 ? E / 64 : 1)), dim3(64), 0, st, src, a.regions,
                                a.group_prefix, a.n_regions, a.exit_tbl, a.gexit, a.str_index);
             LAUNCH_CHECK();
         }
         const bool supers = a.n_supers > 0;
         if (supers) {
-            hipLaunchKernelGGL((k_chain_supers<KIND>), dim3(a.n_supers * (E / 64)), dim3(64), 0, st, src, a.regions,
+            hipLaunchKernelGGL((k_chain_supers<KIND>), dim3(a.n_supers * (E > 64 ? E / 64 : 1)), dim3(64), 0, st, src, a.regions,
                                a.super_prefix, a.n_regions, a.gexit, a.sexit, a.str_index);
             LAUNCH_CHECK();
         }

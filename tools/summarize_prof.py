@@ -29,6 +29,7 @@ def main():
                                                              r["MinNs"], r["MaxNs"], r["Percentage"]))
         lines.append("")
     per = collections.defaultdict(dict)
+    launches = {}
     for name in ("fetch", "write"):
         fs = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))
         if not fs:
@@ -38,6 +39,7 @@ def main():
             agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in agg.items():
             per[k][c] = sum(v) / len(v)
+            launches[k] = len(v)
     traffic = {}
     if per:
         lines += ["## --pmc FETCH_SIZE / WRITE_SIZE (separate passes), average per launch", "",
@@ -51,8 +53,18 @@ def main():
     open(os.path.join(out_dir, "%s_rocprof_summary.md" % tag), "w").write("\n".join(lines))
     tj_path = os.path.join(out_dir, "traffic.json")
     tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
-    if "pqd::k_copy" in traffic:
-        tj[key] = traffic["pqd::k_copy"]
+    # HBM bytes of one decode step: every kernel of the decoder and the memsets between them, weighted by how often
+    # each runs per step (the profiled command runs STEPS_PROFILED steps; copies and fills of the harness around the
+    # timed steps are left out)
+    steps = int(os.environ.get("STEPS_PROFILED", "12"))
+    step_bytes = 0
+    for k, b in traffic.items():
+        if "pqd::" in k or "fillBufferAligned" in k:
+            step_bytes += b * launches.get(k, 0) / steps
+    if step_bytes:
+        tj[key] = int(step_bytes)
+        lines += ["HBM bytes per decode step (all decoder kernels and memsets, %d steps profiled): %d" % (steps, int(step_bytes)), ""]
+        open(os.path.join(out_dir, "%s_rocprof_summary.md" % tag), "w").write("\n".join(lines))
     tj.setdefault("_per_kernel", {})[key] = traffic
     json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)
     print("\n".join(lines))
