@@ -537,18 +537,33 @@ static __device__ __forceinline__ u32 str_len_at(const u32* s_tile, u32 rel) {
 //               position up there).  The first STR_PROBE positions of four tiles are searched at once, 16 lanes per
 //               tile; only tiles that have fewer rows than that (long strings) are searched further, 512 positions
 //               of one tile at a time.
+//   quarters    a walk through a whole tile is a hundred or more dependent LDS round trips while the tile holds its
+//               place in the LDS, and that, not instruction issue, bounds the kernel.  So every tile is cut into
+//               STR_Q quarters; quarters 1.. get rows of their own (their first STR_E2 candidates) and all rows, the
+//               tile's and the quarters', only walk to the end of their quarter.  A tile row then reaches the end of
+//               the tile in at most STR_Q - 1 hops through the quarter rows (a landing that is no quarter row is
+//               walked to the end of its quarter on the spot).
 //   one step    every row's candidate takes one step.  Most rows are done with it: the two positions in front of a
 //               true start jump far (their length has the true length in a high byte) or die.
 //   walks       the others, packed into the lanes of the wave whatever their tile, walk their chain to the end of
-//               the tile through the LDS image: strings started on the way, where the chain leaves the tile (or
-//               ERR_POS: a length that does not fit), and, for pass 2, the chain's first position in every
-//               256-byte block after the row's own.  Rows of one tile that lie on the same chain repeat each
-//               other's steps, which costs nothing: all walks of the wave are one loop.
+//               their quarter through the LDS image: strings started on the way, where the chain leaves the quarter
+//               (or ERR_POS: a length that does not fit), and, for pass 2, the chain's first position in the
+//               quarter's second 256-byte block.  Rows that lie on the same chain repeat each other's steps, which
+//               costs nothing: all walks of the wave are one loop.
 constexpr u32 STR_A = 8;        // tiles per wave
-constexpr u32 STR_PROBE = 128;
-constexpr u32 STR_PAIRS = STR_A * CH_E_STRINGS;  // (tile, row) pairs of a wave
+constexpr u32 STR_PROBE = 128;  // leading positions of a tile searched for its rows in the shared sweep
+constexpr u32 STR_Q = 4, STR_QB = CH_T / STR_Q;  // quarters per tile, bytes per quarter
+constexpr u32 STR_E2 = 4;       // rows of a quarter
+constexpr u32 STR_QPROBE = 64;  // leading positions of a quarter searched for its rows
+constexpr u32 STR_TP = STR_A * CH_E_STRINGS;            // (tile, row) pairs of a wave
+constexpr u32 STR_QP = STR_A * (STR_Q - 1) * STR_E2;    // (tile, quarter, row) pairs
+constexpr u32 STR_PAIRS = STR_TP + STR_QP;
 static_assert(STR_A % 4 == 0, "the probe takes four tiles at a time");
-static_assert(STR_PAIRS % CH_THREADS == 0 && STR_PAIRS <= 256, "whole passes of one lane per pair; a pair index fits in 8 bits");
+static_assert(STR_TP == CH_THREADS, "one lane per tile row");
+static_assert(STR_PAIRS <= 256, "a pair index fits in 8 bits");
+static_assert(STR_QB == 2 * STR_CP_BYTES, "a quarter is two checkpoint blocks");
+static_assert(STR_E2 == 4, "the rows of a quarter are read as one 64-bit word");
+static_assert((STR_A * (STR_Q - 1) * (STR_QPROBE / 8)) % CH_THREADS == 0, "whole sweeps of 8 positions per lane over the quarters");
 static_assert(CH_E_STRINGS % 8 == 0, "a tile's candidate row is read in 16-byte pieces");
 __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                           const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
@@ -560,14 +575,15 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
     __shared__ __attribute__((aligned(16))) u32 s_tile[A * STR_LDS_WORDS];
     __shared__ u32 s_tb[A], s_len[A], s_found[A];
     __shared__ u64 s_src[A];
-    __shared__ unsigned short s_cand[A][E];
-    __shared__ __attribute__((aligned(16))) u32 s_cp[STR_PAIRS][STR_CP];  // 32-bit slots for the LDS atomic
-    __shared__ u32 s_exit[STR_PAIRS], s_queue[STR_PAIRS];
-    __shared__ unsigned short s_cnt[STR_PAIRS];
+    // per pair: tile rows first (t * E + row), then the quarter rows ((t * (Q - 1) + q - 1) * E2 + row behind STR_TP)
+    __shared__ __attribute__((aligned(16))) unsigned short s_start[STR_PAIRS];  // candidate, tile offset; 0xFFFF = none
+    __shared__ u32 s_exit[STR_PAIRS], s_queue[STR_PAIRS];                      // tile offset where the walk ended, or ERR_POS
+    __shared__ unsigned short s_cnt[STR_PAIRS], s_cp1[STR_PAIRS];              // strings started; first position in the quarter's second block
+    __shared__ __attribute__((aligned(16))) unsigned short s_cp[STR_TP][STR_CP];
     const u32 lane = threadIdx.x, t0 = blockIdx.x * A;
     const u32 nt = n_tiles - t0 < A ? n_tiles - t0 : A;
 #pragma unroll
-    for (u32 i = lane; i < STR_PAIRS; i += CH_THREADS) s_cand[i / E][i % E] = 0xFFFF;
+    for (u32 i = lane; i < STR_PAIRS; i += CH_THREADS) s_start[i] = 0xFFFF;
     if (lane < A) {
         u32 tb = 0, len = 0;
         u64 so = 0;
@@ -631,7 +647,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
         while (m && slot < E) {
             const u32 k = __ffs(m) - 1;
             m &= m - 1;
-            s_cand[t][slot++] = (unsigned short)(o + k);
+            s_start[t * E + slot++] = (unsigned short)(o + k);
         }
         if (j == 0) s_found[t] = total;
     }
@@ -667,78 +683,152 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
             while (m && slot < E) {
                 const u32 k = __ffs(m) - 1;
                 m &= m - 1;
-                s_cand[t][slot++] = (unsigned short)(o + k);
+                s_start[t * E + slot++] = (unsigned short)(o + k);
             }
         }
         if (lane == 0) s_found[t] = found;
     }
     __syncthreads();
-    // ---- one step per row, one lane per (tile, row) pair; the chains that stay inside their tile are queued
+    // ---- rows of the quarters: their first STR_E2 candidates among their leading STR_QPROBE positions, 8 lanes each
+    constexpr u32 QL = STR_QPROBE / 8;  // lanes per quarter
+#pragma unroll
+    for (u32 it = 0; it < A * (STR_Q - 1) * QL / CH_THREADS; it++) {
+        const u32 pi = it * (CH_THREADS / QL) + lane / QL, j = lane % QL;  // pi = t * (Q - 1) + q - 1
+        const u32 t = pi / (STR_Q - 1), o = (pi % (STR_Q - 1) + 1) * STR_QB + j * 8;
+        const u32* tl = s_tile + t * STR_LDS_WORDS + o / 4;
+        const u32 x[3] = {tl[0], tl[1], tl[2]};
+        const int room = (int)(s_len[t] - 3 - s_tb[t] - o);
+        u32 m = 0;
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) {
+            const u32 len = (k & 3) ? __builtin_amdgcn_alignbit(x[k / 4 + 1], x[k / 4], (k & 3) * 8) : x[k / 4];
+            const int r = room - (int)k;
+            m |= (u32)(len < (u32)(r > 0 ? r : 0)) << k;
+        }
+        const u32 mine = __popc(m);
+        u32 incl = mine;
+#pragma unroll
+        for (int d = 1; d < (int)QL; d <<= 1) {
+            const u32 y = __shfl_up(incl, d);
+            if (j >= (u32)d) incl += y;
+        }
+        u32 slot = incl - mine;
+        while (m && slot < STR_E2) {
+            const u32 k = __ffs(m) - 1;
+            m &= m - 1;
+            s_start[STR_TP + pi * STR_E2 + slot++] = (unsigned short)(o + k);
+        }
+    }
+    __syncthreads();
+    // ---- one step per row, one lane per pair; the chains that stay inside their quarter are queued
     const u64 lt = (1ull << lane) - 1;
-    const u32x4 none = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     u32 qn = 0;
 #pragma unroll
     for (u32 i0 = 0; i0 < STR_PAIRS; i0 += CH_THREADS) {
-        const u32 i = i0 + lane, t = i / E;
-        const u32 tb = s_tb[t], L = s_len[t];
-        const u32 rlim = t < nt ? (tb + CH_T < L ? CH_T : L - tb) : 0;
-        const u32 c0 = s_cand[t][i % E];
-        *(u32x4*)s_cp[i] = none;
-        *(u32x4*)(s_cp[i] + 4) = none;
+        const u32 i = i0 + lane;
+        const bool in = i < STR_PAIRS;
+        const u32 t = i < STR_TP ? i / E : (i - STR_TP) / ((STR_Q - 1) * STR_E2);
+        const u32 c0 = in ? s_start[i] : 0xFFFF;
         u32 rel = ERR_POS, cnt = 0;
-        if (c0 != 0xFFFF) {  // a candidate is plausible, so its step succeeds
+        bool walk = false;
+        if (c0 != 0xFFFF) {  // a candidate is plausible, so its step succeeds; absent tiles have no candidates
+            const u32 tb = s_tb[t], L = s_len[t];
+            const u32 rlim = tb + CH_T < L ? CH_T : L - tb;
+            const u32 qe = (c0 / STR_QB + 1) * STR_QB, qend = qe < rlim ? qe : rlim;
             rel = c0 + 4 + str_len_at(s_tile + t * STR_LDS_WORDS, c0);
             cnt = 1;
+            walk = rel < qend;
         }
-        const bool walk = rel < rlim;
-        s_exit[i] = rel == ERR_POS ? ERR_POS : tb + rel;
-        s_cnt[i] = (unsigned short)cnt;
+        if (in) {
+            s_exit[i] = rel;
+            s_cnt[i] = (unsigned short)cnt;
+            s_cp1[i] = 0xFFFF;
+        }
         const u64 bal = __ballot(walk);
         if (walk) s_queue[qn + (u32)__popcll(bal & lt)] = i | (rel << 8);
         qn += (u32)__popcll(bal);
     }
     __syncthreads();
-    // ---- walks, 64 chains at a time
+    // ---- walks to the end of the quarter, 64 chains at a time
     for (u32 base = 0; base < qn; base += CH_THREADS) {
         const bool have = base + lane < qn;
         const u32 e = have ? s_queue[base + lane] : 0;
-        const u32 i = e & 0xFF, t = i / E;
+        const u32 i = e & 0xFF;
+        const u32 t = i < STR_TP ? i / E : (i - STR_TP) / ((STR_Q - 1) * STR_E2);
         const u32 tb = s_tb[t], L = s_len[t];
         const u32 rlim = tb + CH_T < L ? CH_T : L - tb;
         // a position needs its four length bytes inside the region: up to there the room is positive and
         // a length is accepted when len < room = L - 3 - position
         const u32 avail = L - tb, room0 = avail - 3, rlim4 = avail < 4 ? 0 : rlim < room0 ? rlim : room0;
+        const u32 c0 = s_start[i];
+        const u32 qe = (c0 / STR_QB + 1) * STR_QB, qend = qe < rlim ? qe : rlim, wend = qend < rlim4 ? qend : rlim4;
+        const u32 odd_lo = qe - STR_CP_BYTES;                  // the quarter's second block
+        const u32 thr = c0 < odd_lo ? odd_lo : 0xFFFFFFFFu;    // a row in the second block has no later block to report
         const u32* tl = s_tile + t * STR_LDS_WORDS;
-        u32* cp = s_cp[i];
-        u32 rel = have ? e >> 8 : ERR_POS, cnt = 1, pb = 0xFFFFFFFFu;
-        while (rel < rlim4) {  // ERR_POS ends the loop too
-            const u32 nb = rel / STR_CP_BYTES;
-            if (nb != pb) cp[nb] = rel;  // positions only grow: the first one of every block
-            pb = nb;
+        u32 rel = have ? e >> 8 : ERR_POS, cnt = 1, c1 = 0xFFFF;
+        while (rel < wend) {  // ERR_POS ends the loop too
+            if (rel >= thr && rel < c1) c1 = rel;  // positions only grow: the first one in the block stays
             const u32 len = str_len_at(tl, rel);  // two aligned words: an unaligned LDS read is slower
             rel = len < room0 - rel ? rel + 4 + len : ERR_POS;
             cnt++;
         }
-        if (rel < rlim) { rel = ERR_POS; cnt++; }  // a start in the last three bytes of the region
+        if (rel < qend) { rel = ERR_POS; cnt++; }  // a start in the last three bytes of the region
         if (have) {
-            s_exit[i] = rel == ERR_POS ? ERR_POS : tb + rel;
+            s_exit[i] = rel;
             s_cnt[i] = (unsigned short)cnt;
+            s_cp1[i] = (unsigned short)c1;
         }
     }
     __syncthreads();
+    // ---- tile rows: from quarter to quarter to the end of the tile; lane = (tile, row)
+    {
+        const u32 t = lane / E;
+        const u32 tb = s_tb[t], L = s_len[t];
+        const u32 rlim = t < nt ? (tb + CH_T < L ? CH_T : L - tb) : 0;
+        const u32 avail = L - tb, room0 = avail - 3, rlim4 = avail < 4 ? 0 : rlim < room0 ? rlim : room0;
+        const u32* tl = s_tile + t * STR_LDS_WORDS;
+        unsigned short* cp = s_cp[lane];
+        *(u32x4*)cp = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        u32 pos = s_exit[lane], cnt = s_cnt[lane];
+        {
+            const u32 c1 = s_cp1[lane];
+            if (c1 != 0xFFFF) cp[c1 / STR_CP_BYTES] = (unsigned short)c1;
+        }
+        while (pos < rlim) {  // pos lies in a later quarter than every position of the chain before it
+            const u32 q = pos / STR_QB;  // >= 1
+            cp[pos / STR_CP_BYTES] = (unsigned short)pos;
+            const u32 rows0 = STR_TP + (t * (STR_Q - 1) + q - 1) * STR_E2;
+            const u64 rows = *(const u64*)(s_start + rows0);
+            u32 slot = STR_E2;
 #pragma unroll
-    for (u32 i0 = 0; i0 < STR_PAIRS; i0 += CH_THREADS) {
-        const u32 i = i0 + lane, t = i / E;
-        if (t >= nt) continue;
-        StrExit x;
-        x.tgt = s_exit[i];
-        x.cnt = s_cnt[i];
-        ((StrExit*)exit_tbl)[(u64)t0 * E + i] = x;
-        const u32x4 lo = *(const u32x4*)s_cp[i], hi = *(const u32x4*)(s_cp[i] + 4);
-        str_cp[(u64)t0 * E + i] = u32x4{(lo.x & 0xFFFFu) | (lo.y << 16), (lo.z & 0xFFFFu) | (lo.w << 16),
-                                        (hi.x & 0xFFFFu) | (hi.y << 16), (hi.z & 0xFFFFu) | (hi.w << 16)};
-        str_cand[(u64)t0 * E + i] = s_cand[t][i % E];
-        if (i % E == 0) { const u32 f = s_found[t]; str_ncand[t0 + t] = (unsigned short)(f < 0xFFFF ? f : 0xFFFF); }
+            for (u32 k = 0; k < STR_E2; k++)
+                if ((u32)((rows >> (16 * k)) & 0xFFFF) == pos) slot = k;
+            if (slot < STR_E2) {
+                const u32 j = rows0 + slot, c1 = s_cp1[j];
+                if (c1 != 0xFFFF) cp[c1 / STR_CP_BYTES] = (unsigned short)c1;
+                cnt += s_cnt[j];
+                pos = s_exit[j];
+            } else {  // no row of the quarter: string by string to its end
+                const u32 qe = (q + 1) * STR_QB, qend = qe < rlim ? qe : rlim, wend = qend < rlim4 ? qend : rlim4;
+                u32 pb = pos / STR_CP_BYTES;
+                while (pos < wend) {
+                    const u32 len = str_len_at(tl, pos);
+                    pos = len < room0 - pos ? pos + 4 + len : ERR_POS;
+                    cnt++;
+                    if (pos < qend && pos / STR_CP_BYTES != pb) { pb = pos / STR_CP_BYTES; cp[pb] = (unsigned short)pos; }
+                }
+                if (pos < qend) { pos = ERR_POS; cnt++; }
+            }
+        }
+        if (t < nt) {
+            StrExit x;
+            x.tgt = pos == ERR_POS ? ERR_POS : tb + pos;
+            x.cnt = cnt;
+            ((StrExit*)exit_tbl)[(u64)t0 * E + lane] = x;
+            str_cp[(u64)t0 * E + lane] = *(const u32x4*)cp;  // own row: no barrier needed
+            str_cand[(u64)t0 * E + lane] = s_start[lane];
+            if (lane % E == 0) { const u32 f = s_found[t]; str_ncand[t0 + t] = (unsigned short)(f < 0xFFFF ? f : 0xFFFF); }
+        }
     }
 }
 
