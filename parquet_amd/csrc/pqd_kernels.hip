@@ -1137,14 +1137,18 @@ static __device__ __forceinline__ u32 hop_group(const Region& R, const GlobalByt
 
 template <int KIND>
 __global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_base, const Region* __restrict__ regions,
-                                                     const u32* __restrict__ group_prefix, u32 n_regions,
+                                                     const u32* __restrict__ group_prefix, u32 n_regions, u32 n_groups,
                                                      const ExitRec* __restrict__ exit_tbl, ExitRec* __restrict__ gexit,
                                                      const StrIndex sx) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     constexpr u32 G = chain_group_tiles(KIND);
-    constexpr u32 BPG = E > 64 ? E / 64 : 1;  // blocks per group: one lane per row, at least one wave
-    const u32 group = blockIdx.x / BPG;
-    const u32 i = (blockIdx.x % BPG) * 64 + threadIdx.x;  // entry row of the group's first tile
+    static_assert(E % 64 == 0 || 64 % E == 0, "whole waves per group or whole groups per wave");
+    // one lane per (group, row): E / 64 waves per group, or 64 / E groups per wave when a table has fewer rows than a wave has lanes
+    constexpr u32 LPG = E < 64 ? E : 64;  // lanes of a wave that work on the same group
+    const u32 gid = blockIdx.x * 64 + threadIdx.x;
+    const u32 group = gid / E;
+    const u32 i = gid % E;  // entry row of the group's first tile
+    if (group >= n_groups) return;
     const u32 ri = find_owner(group_prefix, n_regions, group);
     const Region R = regions[ri];
     const u32 L = R.len;
@@ -1153,16 +1157,18 @@ __global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_
     const GlobalBytes B{src_base + R.src_off};
     const u32 t_first = (group - group_prefix[ri]) * G, n_rt = (L + CH_T - 1) / CH_T;
     const u32 n_scope = n_rt - t_first < G ? n_rt - t_first : G;
-    if (KIND == KIND_STRINGS && i < n_scope) {  // plausible starts in front of every tile of the group
-        u32 acc = 0;
+    if (KIND == KIND_STRINGS && i < LPG) {  // plausible starts in front of every tile of the group
+        u32 n[G];
 #pragma unroll
-        for (u32 t = 0; t < G; t++) {
-            const u32 n = t < n_scope ? sx.ncand[R.tile_base + t_first + t] : 0;  // uniform addresses
-            if (t < i) acc += n;
+        for (u32 t = 0; t < G; t++) n[t] = t < n_scope ? sx.ncand[R.tile_base + t_first + t] : 0;  // same addresses for the group's lanes
+        for (u32 tt = i; tt < n_scope; tt += LPG) {
+            u32 acc = 0;
+#pragma unroll
+            for (u32 t = 0; t < G; t++)
+                if (t < tt) acc += n[t];
+            sx.gpre[R.tile_base + t_first + tt] = (unsigned short)(acc < 0xFFFF ? acc : 0xFFFF);
         }
-        sx.gpre[R.tile_base + t_first + i] = (unsigned short)(acc < 0xFFFF ? acc : 0xFFFF);
     }
-    if (i >= E) return;  // fewer rows than lanes
     u32 p = slot_pos<KIND, 1>(sx, R.tile_base + t_first, g_lo, i, n_scope), cnt = 0;
     u64 vals = 0;
     if (KIND != KIND_STRINGS && p >= g_hi) return;
@@ -2255,8 +2261,8 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
                                    a.tile_prefix, a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn,
                                    a.tile_region);
             LAUNCH_CHECK();
-            hipLaunchKernelGGL((k_chain_groups<KIND>), dim3(a.n_groups * (E > 64 ? E / 64 : 1)), dim3(64), 0, st, src, a.regions,
-                               a.group_prefix, a.n_regions, a.exit_tbl, a.gexit, a.str_index);
+            hipLaunchKernelGGL((k_chain_groups<KIND>), dim3((u32)(((u64)a.n_groups * E + 63) / 64)), dim3(64), 0, st, src, a.regions,
+                               a.group_prefix, a.n_regions, a.n_groups, a.exit_tbl, a.gexit, a.str_index);
             LAUNCH_CHECK();
         }
         const bool supers = a.n_supers > 0;
