@@ -21,7 +21,8 @@ def main():
     out_dir = os.path.join(root, "profiles")
     os.makedirs(out_dir, exist_ok=True)
     lines = ["# rocprofv3 summary %s (workload key %s)" % (tag, key), ""]
-    ks = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
+    newest = lambda paths: sorted(paths, key=os.path.getmtime)[-1:]  # gpurun_out/ keeps the files of earlier runs
+    ks = newest(glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")))
     if ks:
         lines += ["## --kernel-trace --stats", "", "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
         for r in csv.DictReader(open(ks[0])):
@@ -31,7 +32,7 @@ def main():
     per = collections.defaultdict(dict)
     launches = {}
     for name in ("fetch", "write"):
-        fs = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))
+        fs = newest(glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")))
         if not fs:
             continue
         agg = collections.defaultdict(list)
