@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
 
-DECODE_SOURCES = ["pqd_kernels.hip", "pqd_levels.hip", "pqd_encode.hip", "pqd_api.cpp", "pqd_file.cpp", "pqd_multi.cpp"]
+DECODE_SOURCES = ["pqd_kernels.hip", "pqd_levels.hip", "pqd_levels_4k.hip", "pqd_encode.hip", "pqd_api.cpp", "pqd_file.cpp", "pqd_multi.cpp"]
 DECODE_DEPS = DECODE_SOURCES + ["pqd_device.h", "pqd_rle.h", "thrift_compact.h", os.path.join("..", "..", "include", "pqdecode.h")]
 SYNTH_SOURCES = ["pqd_writer.cpp"]
 SYNTH_DEPS = SYNTH_SOURCES + ["thrift_compact.h"]

@@ -88,6 +88,7 @@ struct pqd_plan {
     u8 *ff_begin = nullptr, *zero_begin = nullptr;  // per-run reset ranges
     size_t ff_bytes = 0, zero_bytes = 0;
 
+    u32 lv_tile = LV_T_SMALL_BATCH;  // bytes per super-tile of the level decode: which build of k_levels runs
     u32 n_lvtiles = 0, n_stiles_chain = 0, n_btiles = 0, n_rtiles = 0, n_copy_blocks = 0;
     int64_t bytes_in = 0, copy_bytes = 0;
 
@@ -355,7 +356,19 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         want(PQD_OUT_PAGE_NONNULL, (size_t)C.n_pages * 8);
     }
 
-    // regions
+    // regions.  Super-tile size of the level decode: the 8 KiB build unless the batch is large (see pqd_device.h)
+    {
+        u64 n8 = 0;
+        for (size_t pi = 0; pi < n_pages; pi++)
+            for (int lv = 0; lv < 2; lv++) {
+                const u32 nb = lv == 0 ? rep_bytes[pi] : def_bytes[pi];
+                if (nb) n8 += nb > 4 ? ((u64)nb - 4 + LV_T_SMALL_BATCH - 1) / LV_T_SMALL_BATCH : 1;
+            }
+        pl->lv_tile = n8 > LV_LARGE_BATCH_TILES ? LV_T_LARGE_BATCH : LV_T_SMALL_BATCH;
+        const char* force = getenv("PQD_LV_TILE");  // diagnostics: 4096 or 8192
+        if (force && (atoi(force) == (int)LV_T_LARGE_BATCH || atoi(force) == (int)LV_T_SMALL_BATCH)) pl->lv_tile = (u32)atoi(force);
+    }
+    const u32 lv_tile = pl->lv_tile;
     u64 n_lv = 0;
     pl->stile_chain_prefix.push_back(0);
     pl->sgroup_prefix.push_back(0);
@@ -389,7 +402,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                 R.page = pi;
                 R.count_level = lv == 1 ? (u32)C.max_def : ERR_POS;
                 // every block has at least one super-tile: an empty one still has to report its missing values
-                const u32 n_sup = R.len ? (R.len + LV_T - 1) / LV_T : 1;
+                const u32 n_sup = R.len ? (R.len + lv_tile - 1) / lv_tile : 1;
                 for (u32 t = 0; t < n_sup; t++) pl->lv_order.push_back(LvTile{(u32)pl->lregions.size(), t});
                 pl->lregions.push_back(R);
                 n_lv += n_sup;
@@ -627,7 +640,7 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     }
 
     // levels, then everything that only needs them
-    if (n_lreg) HIP_TRY(ctx, launch_levels(st, src, pl->lv));
+    if (n_lreg) HIP_TRY(ctx, launch_levels(st, src, pl->lv, pl->lv_tile));
     HIP_TRY(ctx, launch_page_scan(st, pl->d_chunks, n_chunks, pl->d_pages, n_pages, pl->d_page_dyn, pl->d_chunk_dyn, pl->d_status));
     HIP_TRY(ctx, launch_value_index(st, pl->d_chunks, pl->d_pages, pl->d_page_dyn, pl->d_vidx_pages, (u32)pl->vidx_pages.size(), pl->d_lvl_off));
     HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, (u32)pl->bool_pages.size(), pl->n_btiles,

@@ -144,8 +144,16 @@ hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Re
 // A super-tile is LV_T chain bytes of one level block and belongs to one workgroup, which resolves the run
 // headers inside it, learns where the true chain enters from the super-tile before it (one 8-byte granule per
 // boundary), and expands its runs straight into the level array.
-constexpr u32 LV_T = 8192;        // chain bytes per super-tile
-constexpr u32 LV_THREADS = 512;   // one 16-byte sub-tile per thread
+// The kernel is built twice (pqd_levels.hip and, through pqd_levels_4k.hip, with PQD_LV_TILE_BYTES = 4096): 8 KiB
+// super-tiles make the hand-off chain of a block short (16 hops per 1M-level page), which is what a small batch
+// waits for; 4 KiB super-tiles (twice the workgroups, half the LDS each) run a large batch 10-20 % faster.
+#ifndef PQD_LV_TILE_BYTES
+#define PQD_LV_TILE_BYTES 8192
+#endif
+constexpr u32 LV_T = PQD_LV_TILE_BYTES;   // chain bytes per super-tile in this translation unit
+constexpr u32 LV_THREADS = LV_T / 16;     // one 16-byte sub-tile per thread
+constexpr u32 LV_T_SMALL_BATCH = 8192, LV_T_LARGE_BATCH = 4096;
+constexpr u32 LV_LARGE_BATCH_TILES = 1536;  // a batch of more 8 KiB super-tiles than this takes the 4 KiB build (two rounds of resident workgroups)
 constexpr u32 LV_SUB = LV_T / LV_THREADS;
 constexpr u32 LV_SPIN_MAX = 1u << 22;  // polls of a granule before a workgroup gives up (safety net, never reached)
 struct LvTile { u32 region, index; };  // launch order: super-tile `index` of `region`; predecessors come first
@@ -161,7 +169,9 @@ struct LvArgs {
     u64* stamps;           // diagnostics only (else null): LV_STAMPS wall-clock stamps (100 MHz) per ticket
 };
 constexpr u32 LV_STAMPS = 16;
-hipError_t launch_levels(hipStream_t st, const u8* src, const LvArgs& a);
+// tile_bytes = LV_T_SMALL_BATCH or LV_T_LARGE_BATCH: the super-tile size the tables of `a` were planned for
+hipError_t launch_levels(hipStream_t st, const u8* src, const LvArgs& a, u32 tile_bytes);
+hipError_t launch_levels_4k(hipStream_t st, const u8* src, const LvArgs& a);  // the second build
 constexpr u32 LV_ALLOW_SHORT = 1;  // Region.otile_base flag on this path: a block with fewer values than n_out is no error
 // one block on its own (widths 0..8, one byte per value); see pqd_levels.hip
 constexpr size_t PQD_NOALLOC_MAX_BLOCK = 16u << 20;  // bytes of runs the entry point without allocations accepts

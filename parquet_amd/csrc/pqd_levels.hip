@@ -36,6 +36,9 @@
 #include "pqd_rle.h"
 
 namespace pqd {
+#if PQD_LV_TILE_BYTES != 8192
+namespace lv4k {  // the second build of the kernel keeps its names apart
+#endif
 
 constexpr u32 LV_PITCH = LV_THREADS + 1;        // entries per memo row (row k = starts at offset k of every sub-tile)
 constexpr u32 LV_MEMO = LV_SUB * LV_PITCH;      // entries per memo table
@@ -44,7 +47,7 @@ constexpr u32 LV_VSAT = 0xFFFF;                 // 16-bit value count: this many
 constexpr u32 LV_GROUP = 256;                   // bytes per hop group
 constexpr u32 LV_GSUB = LV_GROUP / LV_SUB;      // sub-tiles per group
 constexpr u32 LV_NGROUPS = LV_T / LV_GROUP;
-constexpr u32 LV_TC = 512;                      // tabulated entries of a super-tile: its first LV_TC bytes
+constexpr u32 LV_TC = LV_THREADS < 512 ? LV_THREADS : 512;  // tabulated entries of a super-tile: its first LV_TC bytes
 constexpr u32 LV_DENSE_BITS = 65536;            // bits of the dense level stream per expand window
 constexpr u32 LV_DENSE_BIAS = 128;              // the stream starts at this bit: a block may begin up to 15 values before the window
 constexpr u32 LV_DENSE_WORDS = LV_DENSE_BIAS / 32 + LV_DENSE_BITS / 32 + 6;
@@ -652,8 +655,19 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     }
 }
 
-hipError_t launch_levels(hipStream_t st, const u8* src, const LvArgs& a) {
+#if PQD_LV_TILE_BYTES != 8192
+}  // namespace lv4k
+hipError_t launch_levels_4k(hipStream_t st, const u8* src, const LvArgs& a) {
     if (a.n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(lv4k::k_levels, dim3(a.n_tiles), dim3(LV_THREADS), 0, st, src, a);
+    return hipGetLastError();
+}
+}  // namespace pqd
+#else
+hipError_t launch_levels(hipStream_t st, const u8* src, const LvArgs& a, u32 tile_bytes) {
+    if (a.n_tiles == 0) return hipSuccess;
+    if (tile_bytes == LV_T_LARGE_BATCH) return launch_levels_4k(st, src, a);
+    if (tile_bytes != LV_T) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_levels, dim3(a.n_tiles), dim3(LV_THREADS), 0, st, src, a);
     return hipGetLastError();
 }
@@ -738,10 +752,11 @@ hipError_t launch_rle_decode_u8(hipStream_t st, void* sc_, int width, const u8* 
     LvTile* const order = (LvTile*)(sc + sizeof(LvsHead));
     u64* const pos_g = (u64*)(order + n_tiles);
     LvArgs a{&H->region, order, n_tiles, pos_g, pos_g + n_tiles, &H->ticket, nullptr, H->status, nullptr};
-    e = launch_levels(st, runs, a);
+    e = launch_levels(st, runs, a, LV_T);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_lv_finish, dim3(1), dim3(1), 0, st, sc, n_tiles, result_device);
     return hipGetLastError();
 }
 
 }  // namespace pqd
+#endif
