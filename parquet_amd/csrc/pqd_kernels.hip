@@ -551,6 +551,7 @@ static __device__ __forceinline__ u32 str_len_at(const u32* s_tile, u32 rel) {
 //               quarter's second 256-byte block.  Rows that lie on the same chain repeat each other's steps, which
 //               costs nothing: all walks of the wave are one loop.
 constexpr u32 STR_A = 8;        // tiles per wave
+constexpr u32 STR_ITER = 4;     // groups of STR_A tiles per workgroup
 constexpr u32 STR_PROBE = 128;  // leading positions of a tile searched for its rows in the shared sweep
 constexpr u32 STR_Q = 4, STR_QB = CH_T / STR_Q;  // quarters per tile, bytes per quarter
 constexpr u32 STR_E2 = 4;       // rows of a quarter
@@ -580,45 +581,74 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
     __shared__ u32 s_exit[STR_PAIRS], s_queue[STR_PAIRS];                      // tile offset where the walk ended, or ERR_POS
     __shared__ unsigned short s_cnt[STR_PAIRS], s_cp1[STR_PAIRS];              // strings started; first position in the quarter's second block
     __shared__ __attribute__((aligned(16))) unsigned short s_cp[STR_TP][STR_CP];
-    const u32 lane = threadIdx.x, t0 = blockIdx.x * A;
+    // A workgroup takes STR_ITER groups of STR_A tiles one after the other.  Where a tile lies (region index -> region ->
+    // bytes) is two dependent loads before the tile itself can be loaded: those are made once for all groups, and the
+    // tiles of the next group are loaded into registers while the current group is worked on.
+    __shared__ u32 s_mtb[STR_ITER * A], s_mlen[STR_ITER * A];
+    __shared__ u64 s_msrc[STR_ITER * A];
+    static_assert(STR_ITER * A <= CH_THREADS, "one lane per tile of the workgroup for the region lookups");
+    const u32 lane = threadIdx.x, tile_first = blockIdx.x * STR_ITER * A;
+    if (lane < STR_ITER * A) {
+        u32 tb = 0, len = 0;
+        u64 so = 0;
+        const u32 tile = tile_first + lane;
+        if (tile < n_tiles) {
+            const u32 ri = tile_region ? tile_region[tile] : find_owner(tile_prefix, n_regions, tile);
+            const Region R = regions[ri];
+            tb = (tile - tile_prefix[ri]) * CH_T; len = R.len; so = R.src_off;
+        }
+        s_mtb[lane] = tb; s_mlen[lane] = len; s_msrc[lane] = so;  // absent tiles: length 0, nothing is plausible
+    }
+    __syncthreads();
+    // every tile of group `it` complete, lookahead included: its loads can all be in flight at once
+    auto group_whole = [&](u32 it) {
+        if (it >= STR_ITER || tile_first + (it + 1) * A > n_tiles) return false;
+        bool w = true;
+        for (u32 t = 0; t < A; t++) w = w && s_mtb[it * A + t] + CH_T + 4 <= s_mlen[it * A + t];
+        return w;
+    };
+    u32x4 pa[A], pb[A];
+    u32 pahead = 0;
+#pragma unroll
+    for (u32 t = 0; t < A; t++) pa[t] = pb[t] = u32x4{0, 0, 0, 0};
+    auto prefetch = [&](u32 it) {
+#pragma unroll
+        for (u32 t = 0; t < A; t++) {
+            const u8* p = src_base + s_msrc[it * A + t] + s_mtb[it * A + t] + lane * CH_SUB;
+            pa[t] = *(const u32x4_u*)p;
+            pb[t] = *(const u32x4_u*)(p + 16);
+        }
+        if (lane < A) pahead = *(const u32_u*)(src_base + s_msrc[it * A + lane] + s_mtb[it * A + lane] + CH_T);
+    };
+    bool have = group_whole(0);
+    if (have) prefetch(0);
+    for (u32 iter = 0; iter < STR_ITER; iter++) {
+    const u32 t0 = tile_first + iter * A;
+    if (t0 >= n_tiles) break;  // uniform
     const u32 nt = n_tiles - t0 < A ? n_tiles - t0 : A;
 #pragma unroll
     for (u32 i = lane; i < STR_PAIRS; i += CH_THREADS) s_start[i] = 0xFFFF;
     if (lane < A) {
-        u32 tb = 0, len = 0;
-        u64 so = 0;
-        if (lane < nt) {
-            const u32 ri = tile_region ? tile_region[t0 + lane] : find_owner(tile_prefix, n_regions, t0 + lane);
-            const Region R = regions[ri];
-            tb = (t0 + lane - tile_prefix[ri]) * CH_T; len = R.len; so = R.src_off;
+        s_tb[lane] = s_mtb[iter * A + lane]; s_len[lane] = s_mlen[iter * A + lane]; s_src[lane] = s_msrc[iter * A + lane];
+        s_found[lane] = 0;
+    }
+    if (have) {
+#pragma unroll
+        for (u32 t = 0; t < A; t++) {
+            *(u32x4*)(s_tile + t * STR_LDS_WORDS + lane * 8) = pa[t];
+            *(u32x4*)(s_tile + t * STR_LDS_WORDS + lane * 8 + 4) = pb[t];
         }
-        s_tb[lane] = tb; s_len[lane] = len; s_src[lane] = so; s_found[lane] = 0;  // absent tiles: length 0, nothing is plausible
+        if (lane < A) { s_tile[lane * STR_LDS_WORDS + CH_T / 4] = pahead; s_tile[lane * STR_LDS_WORDS + CH_T / 4 + 1] = 0; }
     }
     __syncthreads();
-    bool whole = nt == A;  // every tile complete, lookahead included: all loads can be in flight at once
-    for (u32 t = 0; t < nt; t++) whole = whole && s_tb[t] + CH_T + 4 <= s_len[t];
-    if (whole) {
-        u32x4 a[A], b[A];
-#pragma unroll
-        for (u32 t = 0; t < A; t++) {
-            const u8* p = src_base + s_src[t] + s_tb[t] + lane * CH_SUB;
-            a[t] = *(const u32x4_u*)p;
-            b[t] = *(const u32x4_u*)(p + 16);
-        }
-        u32 ahead = 0;
-        if (lane < A) ahead = *(const u32_u*)(src_base + s_src[lane] + s_tb[lane] + CH_T);
-#pragma unroll
-        for (u32 t = 0; t < A; t++) {
-            *(u32x4*)(s_tile + t * STR_LDS_WORDS + lane * 8) = a[t];
-            *(u32x4*)(s_tile + t * STR_LDS_WORDS + lane * 8 + 4) = b[t];
-        }
-        if (lane < A) { s_tile[lane * STR_LDS_WORDS + CH_T / 4] = ahead; s_tile[lane * STR_LDS_WORDS + CH_T / 4 + 1] = 0; }
-    } else {
+    if (!have) {
         for (u32 t = 0; t < nt; t++) {
             u32 w[8];
             str_stage_tile(src_base + s_src[t], s_len[t], s_tb[t], lane, w, s_tile + t * STR_LDS_WORDS);
         }
     }
+    const bool have_next = group_whole(iter + 1);
+    if (have_next) prefetch(iter + 1);
     __syncthreads();
     // ---- candidates; a position p is one when len < max(L - 3 - p, 0), which is what str_step_win accepts (and is
     // false for p >= L).  First the leading STR_PROBE positions of four tiles at a time, 8 positions per lane.
@@ -829,6 +859,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
             str_cand[(u64)t0 * E + lane] = s_start[lane];
             if (lane % E == 0) { const u32 f = s_found[t]; str_ncand[t0 + t] = (unsigned short)(f < 0xFFFF ? f : 0xFFFF); }
         }
+    }
+    __syncthreads();  // the next group reuses the LDS
+    have = have_next;
     }
 }
 
@@ -1357,121 +1390,10 @@ __global__ void k_chain_tiles(const u8* __restrict__ src_base, const Region* __r
 }
 
 // =====================================================================================
-// k_levels_expand — one block per OT level values of one page: expands the runs that overlap the
-// tile into the dense level array (u8; u16/u32 for the standalone wide decode) and counts
-// def == max_def for the page (valsFromDefs).
+// k_levels_expand<2/4> — the standalone level decode with 16- or 32-bit results (widths up to 32; the page path
+// and the one-byte standalone decode are k_levels in pqd_levels.hip).  One block per OT values: expands the runs
+// that overlap the tile, found through the run table of the chain's marking pass.
 // =====================================================================================
-
-
-// =====================================================================================
-// k_levels_expand8 — the u8 level expand of the page decoder (widths 0..8).  One block per OT level
-// values of one page, one thread per 16 of them.  The runs that overlap the tile are staged in LDS;
-// a thread finds the run that owns its first position by binary search and then decodes run by run:
-// 16 values at a time straight from the page bytes, later runs overwriting the tail of the 16-byte
-// accumulator.  Real encoders emit runs of at least 8 values, so a thread touches at most 3 runs.
-// Also counts def == max_def per tile (valsFromDefs, fields.go:220-228).
-// otile_region[ot] = region of tile ot, with one spare entry; otile_first_run has one spare entry too.
-// =====================================================================================
-__global__ __launch_bounds__(256) void k_levels_expand8(const u8* __restrict__ src_base, const Region* __restrict__ regions,
-                                                        const u32* __restrict__ otile_region,
-                                                        const u32* __restrict__ otile_prefix, u32 n_regions,
-                                                        const RunRec* __restrict__ run_tbl,
-                                                        const u32* __restrict__ otile_first_run,
-                                                        const RegionTotal* __restrict__ totals, u32* __restrict__ otile_cnt) {
-    __shared__ u32 s_out[EX_CAP + 1];
-    __shared__ u32 s_info[EX_CAP];
-    __shared__ u32 s_wave[4];
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 ot = blockIdx.x;
-    // independent loads first: they overlap instead of forming a chain
-    u32 first = otile_first_run[ot];
-    const u32 nf = otile_first_run[ot + 1];
-    u32 ri;
-    bool next_same;
-    if (otile_region) { ri = otile_region[ot]; next_same = otile_region[ot + 1] == ri; }
-    else { ri = find_owner(otile_prefix, n_regions, ot); next_same = ot + 1 < otile_prefix[ri + 1]; }
-    const Region R = regions[ri];
-    const RegionTotal T = totals[ri];
-    const u32 L = R.len, w = R.width;
-    const u8* rsrc = src_base + R.src_off;
-    const u32 n_out = (u32)R.n_out;
-    const u32 t_lo = (ot - R.otile_base) * OT;
-    const u32 t_hi = t_lo + OT < n_out ? t_lo + OT : n_out;
-    if (first == ERR_POS || T.err) return;  // short or corrupt block: status already set
-    const RunRec* runs = run_tbl + R.run_base;
-    // the runs this tile needs end with the run that owns the first value of the next tile
-    u32 last = T.cnt;  // exclusive
-    if (next_same && nf != ERR_POS && nf + 1 < last) last = nf + 1;
-
-    const u32 o0 = t_lo + tid * 16;  // this thread's 16 values
-    u64 acc_lo = 0, acc_hi = 0;
-    u32 cur = t_lo;                  // everything below `cur` is done
-    for (;;) {
-        // stage up to EX_CAP runs starting at `first`; they cover [cur, batch_hi)
-        const u32 m = last - first < EX_CAP ? last - first : EX_CAP;
-        if (m == 0) break;
-        for (u32 i = tid; i < m; i += 256) {
-            const RunRec rr = runs[first + i];
-            s_out[i] = rr.out_off;
-            s_info[i] = rr.info;
-        }
-        if (tid == 0) s_out[m] = first + m < T.cnt ? runs[first + m].out_off : n_out;
-        __syncthreads();
-        const u32 batch_hi = s_out[m] < t_hi ? s_out[m] : t_hi;
-        const u32 lo = o0 > cur ? o0 : cur, hi = o0 + 16 < batch_hi ? o0 + 16 : batch_hi;
-        if (lo < hi) {
-            // last staged run that starts at or before lo (run 0 starts at or before cur); among runs
-            // with equal starts this picks the last, the only one that can hold values
-            u32 a = 0, b = m;
-            while (b - a > 1) {
-                const u32 mid = (a + b) >> 1;
-                if (s_out[mid] <= lo) a = mid; else b = mid;
-            }
-            u32 r = a;
-            do {
-                const u32 so = s_out[r], se = s_out[r + 1];
-                const u32 start = so > lo ? so : lo;
-                if (se > start) merge16(acc_lo, acc_hi, run16(rsrc, L, w, so, s_info[r], start), start - o0);
-                r++;
-            } while (r < m && s_out[r] < hi);
-        }
-        if (batch_hi >= t_hi) break;
-        // next batch starts with the run that owns position batch_hi
-        first += m;
-        cur = batch_hi;
-        __syncthreads();  // the staged runs are rewritten
-    }
-
-    // store + count
-    u32 n_mine = 0;
-    if (o0 < t_hi) n_mine = t_hi - o0 < 16 ? t_hi - o0 : 16;
-    u8* dst = R.out + o0;
-    if (n_mine == 16) {
-        // one 16-byte store at whatever alignment the page's first level has inside the chunk's array
-        u32x4 v;
-        v.x = (u32)acc_lo; v.y = (u32)(acc_lo >> 32); v.z = (u32)acc_hi; v.w = (u32)(acc_hi >> 32);
-        *(u32x4_u*)dst = v;
-    } else {
-        for (u32 k = 0; k < n_mine; k++) dst[k] = (u8)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8)));
-    }
-    if (R.count_level != ERR_POS) {
-        // bytes equal to count_level: XOR, then detect zero bytes
-        const u64 cl = (u64)(R.count_level & 0xFF) * 0x0101010101010101ull;
-        const u64 keep_lo = n_mine >= 8 ? ~0ull : (n_mine ? (1ull << (8 * n_mine)) - 1 : 0);
-        const u64 keep_hi = n_mine >= 16 ? ~0ull : (n_mine > 8 ? (1ull << (8 * (n_mine - 8))) - 1 : 0);
-        auto zero_bytes = [](u64 x) {  // 0x80 in every byte of x that is zero
-            return ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) & 0x8080808080808080ull;
-        };
-        u32 c = __popcll(zero_bytes(acc_lo ^ cl) & keep_lo) + __popcll(zero_bytes(acc_hi ^ cl) & keep_hi);
-        for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
-        // one count per tile, summed per page by k_page_nn (no same-address atomics)
-        if (lane == 0) s_wave[wv] = c;
-        __syncthreads();
-        if (tid == 0) otile_cnt[ot] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    }
-}
-
-// The wide variant (u16 / u32 results, widths up to 32) behind the standalone level decode.
 template <int ESZ>
 __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                        const u32* __restrict__ otile_prefix, u32 n_regions,
@@ -1624,7 +1546,7 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
             };
             u32 c = __popcll(zero_bytes(acc_lo ^ cl) & keep_lo) + __popcll(zero_bytes(acc_hi ^ cl) & keep_hi);
             for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
-            // one count per tile, summed per page by k_page_nn (no same-address atomics)
+            // one count per tile (no same-address atomics); the standalone decode passes no counter array
             __syncthreads();
             if (lane == 0) s_wave[wv] = c;
             __syncthreads();
@@ -1641,19 +1563,6 @@ __global__ __launch_bounds__(256) void k_levels_expand(const u8* __restrict__ sr
     }
 }
 
-// Sums the per-tile counts of def == max_def into the page's non-null count (valsFromDefs).
-__global__ __launch_bounds__(64) void k_page_nn(const Region* __restrict__ regions, const u32* __restrict__ otile_prefix,
-                                                u32 n_regions, const u32* __restrict__ otile_cnt,
-                                                const RegionTotal* __restrict__ totals, PageDyn* __restrict__ page_dyn) {
-    const u32 r = blockIdx.x;
-    const Region R = regions[r];
-    if (R.count_level == ERR_POS) return;
-    u32 c = 0;
-    if (!totals[r].err)
-        for (u32 t = otile_prefix[r] + threadIdx.x; t < otile_prefix[r + 1]; t += 64) c += otile_cnt[t];
-    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
-    if (threadIdx.x == 0) page_dyn[R.page].nn = c;
-}
 
 // =====================================================================================
 // k_page_scan — one wave per chunk: running sums over its pages of the non-null counts (dense
@@ -2252,7 +2161,7 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
     if (phase == 0) {
         if (a.n_tiles) {
             if constexpr (KIND == KIND_STRINGS)
-                hipLaunchKernelGGL(k_str_exits, dim3((a.n_tiles + STR_A - 1) / STR_A), dim3(CH_THREADS), 0, st, src, a.regions,
+                hipLaunchKernelGGL(k_str_exits, dim3((a.n_tiles + STR_A * STR_ITER - 1) / (STR_A * STR_ITER)), dim3(CH_THREADS), 0, st, src, a.regions,
                                    a.tile_prefix, a.n_regions, a.n_tiles, a.exit_tbl, (u32x4*)a.str_cp, a.tile_region,
                                    (unsigned short*)a.str_index.cand,
                                    (unsigned short*)a.str_index.ncand);
@@ -2310,20 +2219,14 @@ hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Re
                                 const u32* otile_prefix, u32 n_regions, u32 n_otiles, const RunRec* run_tbl,
                                 const u32* otile_first_run, const RegionTotal* totals, u32* otile_cnt, PageDyn* page_dyn) {
     if (n_otiles == 0) return hipSuccess;
-    if (esz == 1)
-        hipLaunchKernelGGL(k_levels_expand8, dim3(n_otiles), dim3(256), 0, st, src, regions, otile_region, otile_prefix, n_regions,
-                           run_tbl, otile_first_run, totals, otile_cnt);
-    else if (esz == 2)
+    if (esz == 1) return hipErrorInvalidValue;  // one byte per value is k_levels (launch_rle_decode_u8)
+    if (esz == 2)
         hipLaunchKernelGGL((k_levels_expand<2>), dim3(n_otiles), dim3(256), 0, st, src, regions, otile_prefix, n_regions, run_tbl,
                            otile_first_run, totals, otile_cnt);
     else
         hipLaunchKernelGGL((k_levels_expand<4>), dim3(n_otiles), dim3(256), 0, st, src, regions, otile_prefix, n_regions, run_tbl,
                            otile_first_run, totals, otile_cnt);
     LAUNCH_CHECK();
-    if (otile_cnt) {
-        hipLaunchKernelGGL(k_page_nn, dim3(n_regions), dim3(64), 0, st, regions, otile_prefix, n_regions, otile_cnt, totals, page_dyn);
-        LAUNCH_CHECK();
-    }
     return hipSuccess;
 }
 
