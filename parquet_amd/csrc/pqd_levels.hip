@@ -57,7 +57,7 @@ constexpr u32 LV_TAIL_MAX = 4096;               // bit-packed values past NumVal
 static_assert(LV_SUB == 16, "window loads, memo index and group rounds assume 16-byte sub-tiles");
 static_assert(LV_GSUB * 4 == 64, "one wave = four groups in the group rounds");
 static_assert(LV_TC <= LV_THREADS, "one thread per tabulated entry");
-static_assert(LV_MEMO * 4 >= ((LV_DENSE_WORDS + 3) & ~3u) * 4 + LV_T + 8, "the dense stream and the byte image reuse the sweep memo");
+static_assert(LV_MEMO * 4 >= ((LV_DENSE_WORDS + 3) & ~3u) * 4 + LV_T + 16 + LV_THREADS * 4, "the dense stream, the byte image and the anchors reuse the sweep memo");
 
 static __device__ __forceinline__ u32 lv_idx(u32 rel) { return (rel & (LV_SUB - 1)) * LV_PITCH + (rel >> 4); }
 
@@ -168,7 +168,7 @@ static __device__ __forceinline__ u32 lv_word_bits(u32 jw, u32 bb0, u32 bb1, boo
     u32 x;
     if (is_bp) {
         const int64_t S = (int64_t)sb0 + (int64_t)(jw * 32) - (int64_t)bb0;  // packed bit that lands on bit 0 of word jw
-        const u64 sbit = S >= 0 ? (u64)S : sb0;
+        const u64 sbit = S >= 0 ? (u64)S : 0;  // S < 0: packed bit 0 lands on bit -S of the word (what lies below bb0 is masked off)
         const u64 byte = (u64)py + (sbit >> 3);
         if (byte <= (u64)se) {  // inside the image (py >= sb): two of its words hold the 39 bits needed
             const u32 rb = (u32)byte - sb, sh = (rb & 3) * 8 + ((u32)sbit & 7);
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     __shared__ unsigned short s_tc[LV_TC], s_entry[LV_THREADS], s_gentry[LV_NGROUPS];
     __shared__ u32 s_wc[LV_WAVES];
     __shared__ u64 s_wv[LV_WAVES];
-    __shared__ u32 s_ticket, s_e, s_ex, s_prefix, s_bad, s_fill;
+    __shared__ u32 s_ticket, s_e, s_ex, s_prefix, s_bad, s_fill, s_anch;
     u32* const memo0 = s_memo;
     unsigned short* const la = s_la;
 
@@ -391,6 +391,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     // the super-tile's bytes go to LDS: the true runs are parsed from there
     u32* const dense = s_memo;                                  // LV_DENSE_WORDS
     u32* const img = dense + ((LV_DENSE_WORDS + 3) & ~3u);      // LV_T / 4 + 2 words: the super-tile and 8 bytes behind it
+    u32* const anch = img + LV_T / 4 + 4;                       // LV_THREADS words, see 7a
     *(u32x4*)(img + tid * 4) = u32x4{w[0], w[1], w[2], w[3]};
     if (tid == LV_THREADS - 1) { img[LV_T / 4] = w[4]; img[LV_T / 4 + 1] = w[5]; }
     __syncthreads();
@@ -494,6 +495,8 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
         const u32 W1 = U - W0 < V ? U : W0 + V;
         const u32 n_words = LV_DENSE_BIAS / 32 + ((W1 - W0) * width + 31) / 32 + 6;  // a few spare words: blocks read past the end
         for (u32 i = tid; i < n_words; i += LV_THREADS) dense[i] = 0;
+        anch[tid] = 0;
+        if (tid == 0) s_anch = 0;
         __syncthreads();
         // ---- 7a. assemble: every thread parses its runs; the loop has the same trip count for all lanes of a
         // wave because a very long run is written by all of them
@@ -508,6 +511,23 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
                 if (accn > 32 && (u32)(acc >> 32)) atomicOr(&dense[accw + 1], (u32)(acc >> 32));
                 acc = 0;
                 accn = 0;
+            };
+            auto acc_seek = [&](u32 bit) {  // the next bits appended go to stream bit `bit`
+                if (accn == 0 || accw * 32 + accn != bit) {
+                    acc_flush();
+                    accw = bit >> 5;
+                    accn = bit & 31;
+                }
+            };
+            auto append = [&](u32 bits, u32 n) {
+                acc |= (u64)bits << accn;
+                accn += n;
+                if (accn >= 32) {
+                    if ((u32)acc) atomicOr(&dense[accw], (u32)acc);
+                    acc >>= 32;
+                    accw++;
+                    accn -= 32;
+                }
             };
             for (;;) {
                 const bool act = q < sub_hi && q < L;
@@ -537,37 +557,55 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
                             pay = info >> 1;
                             sbit0 = (u64)(s - ra) * width;
                         }
-                        is_long = live && (((b0 & 31) + nbits + 31) >> 5) > LV_SEG_SERIAL;
+                        u32 bits_left = nbits;  // what this thread still has to put into the stream itself
+                        if (bp && s == ra && t == rb && nbits > 64) {
+                            // A bit-packed run that lies in the window as a whole is its packed bytes, copied.  This thread
+                            // copies the ones in its own 16 bytes; the threads of the sub-tiles behind it copy theirs (7a',
+                            // told where through `anch`: stream bit | bytes << 17 | first byte << 22); what lies behind the
+                            // super-tile is left to this thread again.
+                            const u32 plen = nbits >> 3, pr = pay - sb, own_end = (tid + 1) * LV_SUB;
+                            const u32 own = pr >= own_end ? 0 : (own_end - pr < plen ? own_end - pr : plen);
+                            u32 done = own, pos = pr + own, obit = b0 + 8 * own;
+                            while (done < plen && pos < LV_T) {
+                                const u32 sub = pos / LV_SUB, skip = pos % LV_SUB;
+                                const u32 nb = LV_SUB - skip < plen - done ? LV_SUB - skip : plen - done;
+                                anch[sub] = obit | (nb << 17) | (skip << 22);
+                                s_anch = 1;
+                                obit += 8 * nb; pos += nb; done += nb;
+                            }
+                            if (own) {
+                                acc_seek(b0);
+                                u64 sbit = 0;
+                                for (u32 rem = 8 * own; rem;) {
+                                    const u32 take = rem < 32 ? rem : 32;
+                                    const u32 rbt = pr + (u32)(sbit >> 3), sh = (rbt & 3) * 8;  // inside the image
+                                    append(__builtin_amdgcn_alignbit(img[(rbt >> 2) + 1], img[rbt >> 2], sh) & (0xFFFFFFFFu >> (32 - take)), take);
+                                    sbit += take;
+                                    rem -= take;
+                                }
+                            }
+                            b0 += 8 * done;
+                            sbit0 += 8 * (u64)done;
+                            bits_left = nbits - 8 * done;
+                            live = bits_left != 0;
+                        }
+                        is_long = live && (((b0 & 31) + bits_left + 31) >> 5) > LV_SEG_SERIAL;
                         if (live && !is_long) {
                             // the run's bits join the accumulator, at most 32 at a time
-                            if (accn == 0 || accw * 32 + accn != b0) {
-                                acc_flush();
-                                accw = b0 >> 5;
-                                accn = b0 & 31;
-                            }
-                            auto append = [&](u32 bits, u32 n) {
-                                acc |= (u64)bits << accn;
-                                accn += n;
-                                if (accn >= 32) {
-                                    if ((u32)acc) atomicOr(&dense[accw], (u32)acc);
-                                    acc >>= 32;
-                                    accw++;
-                                    accn -= 32;
-                                }
-                            };
+                            acc_seek(b0);
                             if (!bp) {
                                 u32 ph = 0;
-                                for (u32 rem = nbits; rem;) {
+                                for (u32 rem = bits_left; rem;) {
                                     const u32 take = rem < 32 ? rem : 32;
                                     append((u32)(pat >> ph) & (0xFFFFFFFFu >> (32 - take)), take);
                                     rem -= take;
                                     if (odd_w) { ph += 32 % width; if (ph >= width) ph -= width; }
                                 }
-                            } else if (nbits <= 32 && pay_ok && s == ra) {
-                                append(pay32 & (0xFFFFFFFFu >> (32 - nbits)), nbits);  // the packed bits are in my registers
+                            } else if (bits_left <= 32 && pay_ok && s == ra && bits_left == nbits) {
+                                append(pay32 & (0xFFFFFFFFu >> (32 - bits_left)), bits_left);  // the packed bits are in my registers
                             } else {
                                 u64 sbit = sbit0;
-                                for (u32 rem = nbits; rem;) {
+                                for (u32 rem = bits_left; rem;) {
                                     const u32 take = rem < 32 ? rem : 32;
                                     const u64 byte = (u64)pay + (sbit >> 3);
                                     u32 x;
@@ -601,8 +639,30 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
                 if (act) q = nxt;
             }
             acc_flush();
-        }
-        __syncthreads();
+            // ---- 7a'. packed bytes of runs that started in an earlier sub-tile: every thread copies its own
+            __syncthreads();
+            const u32 an = s_anch ? anch[tid] : 0;  // s_anch is the same for all threads: no anchors, no second barrier
+            if (an) {
+                const u32 obit = an & 0x1FFFF, nb = (an >> 17) & 31, r = tid * LV_SUB + (an >> 22);
+                const u32 d = r >> 2, sh = (r & 3) * 8, j0 = obit >> 5, s2 = obit & 31;
+                u32 raw[5], x[4];
+#pragma unroll
+                for (int k = 0; k < 5; k++) raw[k] = img[d + k];  // at most 2 words behind the image: masked off below
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const u32 have = nb > 4u * k ? nb - 4u * k : 0;  // bytes of word k that belong to the run
+                    const u32 v = __builtin_amdgcn_alignbit(raw[k + 1], raw[k], sh);
+                    x[k] = have >= 4 ? v : have ? v & ((1u << (8 * have)) - 1) : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const u32 lo = k ? x[k - 1] : 0, hi = k < 4 ? x[k] : 0;
+                    const u32 o = s2 ? __builtin_amdgcn_alignbit(hi, lo, 32 - s2) : hi;
+                    if (o) atomicOr(&dense[j0 + k], o);
+                }
+            }
+            if (s_anch) __syncthreads();
+        } else __syncthreads();
         LV_STAMP(12);
         // ---- 7b. unpack [W0, W1) to level indices [g_lo, g_hi): blocks of 16 values at 16-byte aligned addresses
         const u32 g_lo = prefix + W0, g_hi = prefix + W1;
