@@ -99,13 +99,15 @@ static __device__ __forceinline__ void lv_header4(u32 lo, u32 p, u32 L, u32 w, u
 // and how to produce them: info = value << 1 for an RLE run (width <= 8), position of the packed bytes << 1 | 1
 // for a bit-packed run, whose first 32 packed bits are pay32 when pay_ok.
 static __device__ __forceinline__ void lv_run(const u32* img, u32 r, u32 q, u32 L, u32 width, u32& nxt, u32& vals, u32& info,
-                                              u32& pay32, bool& pay_ok) {
+                                              u32& pay32, bool& pay_ok, u64* pay64 = nullptr, u32* pay_bits = nullptr) {
     u32 lo, hi, b8, n;
     bool bp;
     lv_win_img(img, r, lo, hi, b8);
     lv_header4(lo, q, L, width, n, nxt, vals, bp);
     if (n) {
-        const u32 after = (u32)((lo | ((u64)hi << 32)) >> (8 * n));  // the 4 bytes behind the header
+        const u64 after64 = (lo | ((u64)hi << 32)) >> (8 * n);  // the 8 - n bytes behind the header
+        const u32 after = (u32)after64;
+        if (pay64) { *pay64 = after64; *pay_bits = 64 - 8 * n; }
         pay32 = after;
         pay_ok = true;
         info = bp ? (width ? ((q + n) << 1) | 1u : 0u) : (width ? (after & 0xFF) << 1 : 0u);  // width 0: runs of zeros
@@ -113,6 +115,7 @@ static __device__ __forceinline__ void lv_run(const u32* img, u32 r, u32 q, u32 
         rle_step_w32(lo, hi, q, L, width, nxt, vals, info);
         pay32 = 0;
         pay_ok = false;
+        if (pay64) { *pay64 = 0; *pay_bits = 0; }
         if (!(info & 1)) {
             const u32 d = (info >> 1) - q;  // the value byte sits 5..8 bytes after q
             u32 val = 0;
@@ -536,11 +539,33 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
                 u64 pat = 0, sbit0 = 0;
                 bool bp = false, is_long = false;
                 if (act) {
-                    u32 info, pay32;
+                    u32 info, pay32, pay_bits;
+                    u64 pay64;
                     bool pay_ok;
-                    lv_run(img, q - sb, q, L, width, nxt, vals, info, pay32, pay_ok);
+                    lv_run(img, q - sb, q, L, width, nxt, vals, info, pay32, pay_ok, &pay64, &pay_bits);
                     const u64 rb = ra + vals;
-                    if (vals && ra < W1 && rb > W0) {
+                    // the usual run: short, in the window as a whole, its bits at hand (an RLE value, or packed bytes
+                    // that came with the header): two appends at most, no loops
+                    const u32 nb_all = vals <= 64 ? __umul24(vals, width) : 0xFFFFFFFFu;
+                    const bool quick = vals && ra >= W0 && rb <= W1 && nb_all <= ((info & 1) ? pay_bits : 64u) &&
+                                       !(ra == W0 && rb == W1);
+                    if (quick) {
+                        const u32 qb0 = LV_DENSE_BIAS + __umul24((u32)ra - W0, width);
+                        u64 bits;
+                        if (info & 1) bits = pay64;
+                        else {
+                            const u32 v = info >> 1;
+                            if (rep_mul) { const u32 p32 = v * (u32)rep_mul; bits = p32 | ((u64)p32 << 32); }  // width 1, 2, 4 or 8
+                            else { bits = v; for (u32 sft = width; sft < 64; sft <<= 1) bits |= bits << sft; }
+                        }
+                        if (nb_all < 64) bits &= (1ull << nb_all) - 1;
+                        if (bits) {  // zeros are there already
+                            acc_seek(qb0);
+                            const u32 n1 = nb_all < 32 ? nb_all : 32;
+                            append((u32)bits, n1);
+                            if (nb_all > 32) append((u32)(bits >> 32), nb_all - 32);
+                        }
+                    } else if (vals && ra < W1 && rb > W0) {
                         const u32 s = ra > W0 ? (u32)ra : W0, t = rb < W1 ? (u32)rb : W1;
                         b0 = LV_DENSE_BIAS + (s - W0) * width;
                         b1 = LV_DENSE_BIAS + (t - W0) * width;
