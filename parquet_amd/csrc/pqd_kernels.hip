@@ -474,7 +474,7 @@ __global__ __launch_bounds__(NT) void k_chain(const u8* __restrict__ src_base, c
 // =====================================================================================
 // PLAIN BYTE_ARRAY chains.  A length prefix is cheap to parse and a wrong start dies fast (a random
 // length overshoots the page), so strings do not need the every-byte sweep of k_chain:
-//   k_str_exits   pass 1: the rows of a tile's exit table are its first 64 plausible string starts (positions
+//   k_str_exits   pass 1: the rows of a tile's exit table are its first CH_E_STRINGS plausible string starts (positions
 //                 whose four bytes are a length that fits in the page), wherever they lie in the tile; for
 //                 each, where its chain leaves the tile and how many strings it passes.  Same hop kernels
 //                 as the level chains, with the row of an entry looked up through StrIndex.
@@ -1047,8 +1047,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
 // `tile`).  Levels and snappy elements: the tables hold the first E byte positions.  Strings: the tables hold
 // the first E PLAUSIBLE string starts of the tile (positions whose four bytes are a length that fits in the
 // page), so that an entry anywhere in the tile is tabulated, not just one in its first bytes: strings longer
-// than a few dozen bytes enter a tile anywhere.  StrIndex::map has one 16-bit word per 8 positions: the
-// plausibility bits and, above them, the number of plausible positions in front of the word.
+// than a few dozen bytes enter a tile anywhere.  StrIndex::cand holds the rows' positions in ascending order:
+// a position is looked up by comparing it with all of them (16 bytes per 8 rows).
 // The tables of a group (LEVEL 1) and of a super-group (LEVEL 2) hold the first E plausible starts of ALL their
 // tiles, so that a chain of strings longer than a tile, which enters most groups beyond their first tile, is
 // still tabulated: a start's row there is its row in its own tile plus the plausible starts of the group's
