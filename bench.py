@@ -428,7 +428,7 @@ def main():
         if world == 1 and not args.no_extras and args.workload == "mixed":
             # the single-config workloads on smaller files, same run, same checks
             extras = {}
-            for wl, (pg, rgs) in (("flat", (16, 2)), ("optint", (16, 2)), ("optstr", (8, 2)), ("nested", (8, 2))):
+            for wl, (pg, rgs) in (("flat", (32, 2)), ("optint", (32, 2)), ("optstr", (16, 2)), ("nested", (16, 2))):
                 e = Loaded(ctx, wl, list(range(rgs)), pg, args.rows_per_page)
                 el, sm, _ = timed(e, 50, 3)
                 bi, bo, _ = e.plan.bytes()
