@@ -401,6 +401,10 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                 R.out = (u8*)(uintptr_t)lvl_off[pi];  // patched with the array base below
                 R.page = pi;
                 R.count_level = lv == 1 ? (u32)C.max_def : ERR_POS;
+                if (lv == 0) {  // repetition levels: the decode also leaves the bitmap of rep == 0 for the row offsets
+                    R.count_level = 0;
+                    R.otile_base |= LV_BITMAP_ONLY;
+                }
                 // every block has at least one super-tile: an empty one still has to report its missing values
                 const u32 n_sup = R.len ? (R.len + lv_tile - 1) / lv_tile : 1;
                 for (u32 t = 0; t < n_sup; t++) pl->lv_order.push_back(LvTile{(u32)pl->lregions.size(), t});
@@ -487,6 +491,9 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     // validity bitmaps: the level kernel ORs the words that two workgroups share
     for (size_t c = 0; c < n_chunks; c++)
         if (pl->chunks[c].max_def > 0) off_out[c * N_OUT + PQD_OUT_VALIDITY] = ap.take(pl->outs[c].cap[PQD_OUT_VALIDITY] + 64);
+    std::vector<size_t> off_rstarts(n_chunks, (size_t)-1);  // row-start bitmaps of the repeated chunks, same treatment
+    for (size_t c = 0; c < n_chunks; c++)
+        if (pl->chunks[c].max_rep > 0) off_rstarts[c] = ap.take((pl->chunks[c].n_levels + 7) / 8 + 64);
     const size_t o_status = ap.take(16);
     const size_t o_lvticket = ap.take(16);
     const size_t o_lvpos = ap.take((size_t)pl->n_lvtiles * 8), o_lvval = ap.take((size_t)pl->n_lvtiles * 8);  // hand-off granules
@@ -514,13 +521,15 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
             *ptrs[w] = o == (size_t)-1 ? nullptr : A + o;
             pl->outs[c].p[w] = *ptrs[w];
         }
+        C.row_starts = off_rstarts[c] == (size_t)-1 ? nullptr : A + off_rstarts[c];
     }
     for (Region& R : pl->lregions) {
         const ChunkRec& C = pl->chunks[pl->pages[R.page].chunk];
         const u64 lo = (u64)(uintptr_t)R.out;
-        R.out = (R.count_level == ERR_POS ? C.reps : C.defs) + lo;
-        R.run_base = lo;                                            // level index of the page's first level in its chunk
-        R.out2 = R.count_level == ERR_POS ? nullptr : C.validity;   // definition levels also yield the validity bitmap
+        const bool is_rep = (R.otile_base & LV_BITMAP_ONLY) != 0;
+        R.out = (is_rep ? C.reps : C.defs) + lo;
+        R.run_base = lo;                                // level index of the page's first level in its chunk
+        R.out2 = is_rep ? C.row_starts : C.validity;    // the levels also yield a bitmap: rep == 0 / def == max_def
     }
     for (Region& R : pl->sregions) {
         R.out = pl->chunks[pl->pages[R.page].chunk].offsets;

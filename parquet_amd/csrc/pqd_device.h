@@ -99,6 +99,7 @@ struct ChunkRec {
     u64 stream_len;   // sum of the pages' values-region lengths
     u64 req_values;   // required chunk: parquet.Page.N, the number of values the typed Read takes
     u8 *defs, *reps, *values, *offsets, *chars, *validity, *page_nonnull, *row_level_off, *row_value_off, *value_index;
+    u8* row_starts;   // repeated chunks: bit i = level i has repetition level 0 (written by the level decode, read by k_rows)
 };
 struct ChunkDyn {
     u64 n_values, chars, n_rows;
@@ -173,6 +174,7 @@ constexpr u32 LV_STAMPS = 16;
 hipError_t launch_levels(hipStream_t st, const u8* src, const LvArgs& a, u32 tile_bytes);
 hipError_t launch_levels_4k(hipStream_t st, const u8* src, const LvArgs& a);  // the second build
 constexpr u32 LV_ALLOW_SHORT = 1;  // Region.otile_base flag on this path: a block with fewer values than n_out is no error
+constexpr u32 LV_BITMAP_ONLY = 2;  // ... the bitmap of level == count_level goes to out2, nothing is counted or refused (repetition levels)
 // one block on its own (widths 0..8, one byte per value); see pqd_levels.hip
 constexpr size_t PQD_NOALLOC_MAX_BLOCK = 16u << 20;  // bytes of runs the entry point without allocations accepts
 hipError_t lv_scratch_init(int device);

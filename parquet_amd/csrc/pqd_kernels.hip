@@ -2007,29 +2007,36 @@ __global__ void k_level_block_sizes(const u8* __restrict__ src, const PageRec* _
 }
 
 // =====================================================================================
-// Validity bitmap and per-row offsets.  A row starts at every level with rep == 0 (every level when
-// the column is not repeated); its value offset is the number of def == max_def before it.
+// Per-row offsets of repeated columns.  A row starts at every level with rep == 0; its value offset is the number
+// of def == max_def before it.  Both come as bitmaps from the level decode (ChunkRec::row_starts, ::validity).
 //   k_rows_count   per tile of RT levels: row starts and non-null counts (+ validity words)
 //   k_rows_scan    one block per chunk: exclusive scan of the tile counts
 //   k_rows_write   per tile: writes row_level_off / row_value_off
 // =====================================================================================
-static __device__ __forceinline__ u32 eq_mask16(u32x4 v, u32 level) {
-    u32 m = 0;
-    const u32 wds[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) m |= (u32)(((wds[i] >> (8 * b)) & 0xFF) == level) << (4 * i + b);
-    return m;
-}
-
-static __device__ __forceinline__ u32x4 load16_guarded(const u8* p, u64 i, u64 n) {
-    // p is 16-byte aligned at i == 0 and i % 16 == 0
-    if (i + 16 <= n) return *(const u32x4*)(p + i);
-    u32 wds[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // 0xFF never equals a level <= 8 bits wide that counts
-    for (u32 k = 0; i + k < n && k < 16; k++) wds[k >> 2] = (wds[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | ((u32)p[i + k] << (8 * (k & 3)));
-    u32x4 v; v.x = wds[0]; v.y = wds[1]; v.z = wds[2]; v.w = wds[3];
-    return v;
+// Row starts and non-null levels of every tile of RT levels: one wave per tile, 64 levels per lane from the bitmaps.
+__global__ __launch_bounds__(256) void k_rows_count(const ChunkRec* __restrict__ chunks, const u32* __restrict__ rtile_prefix,
+                                                    const u32* __restrict__ chunk_ids, u32 n_rchunks, u32 n_rtiles,
+                                                    RowTile* __restrict__ tiles) {
+    static_assert(RT == 64 * 64, "one 64-bit word of each bitmap per lane");
+    const u32 lane = threadIdx.x & 63, rt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rt >= n_rtiles) return;
+    const u32 k = find_owner(rtile_prefix, n_rchunks, rt);
+    const ChunkRec C = chunks[chunk_ids[k]];
+    const u64 n = C.n_levels;
+    const u64 i0 = (u64)(rt - rtile_prefix[k]) * RT + lane * 64;
+    u64 valid = 0, starts = 0;
+    if (i0 < n) {
+        const u64 in_range = n - i0 >= 64 ? ~0ull : (1ull << (n - i0)) - 1;
+        // the arrays are padded to whole 64-bit words, but not aligned to them: two 32-bit loads each
+        const u32* pv = (const u32*)C.validity + (i0 >> 5);
+        const u32* ps = (const u32*)C.row_starts + (i0 >> 5);
+        valid = (pv[0] | ((u64)pv[1] << 32)) & in_range;
+        starts = (ps[0] | ((u64)ps[1] << 32)) & in_range;
+        if (i0 == 0) starts |= 1;  // the first level opens a row whatever its rep level (write_repeated.go:62-80)
+    }
+    u32 r = (u32)__popcll(starts), v = (u32)__popcll(valid);
+    for (int d = 32; d > 0; d >>= 1) { r += __shfl_down(r, d); v += __shfl_down(v, d); }
+    if (lane == 0) { tiles[rt].rows = r; tiles[rt].vals = v; }
 }
 
 template <bool WRITE>
@@ -2045,8 +2052,9 @@ __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunk
     u32 valid = 0, starts = 0;
     if (i0 < n) {
         const u32 in_range = n - i0 >= 16 ? 0xFFFFu : (1u << (n - i0)) - 1;
-        valid = eq_mask16(load16_guarded(C.defs, i0, n), (u32)C.max_def) & in_range;
-        starts = C.max_rep > 0 ? eq_mask16(load16_guarded(C.reps, i0, n), 0) & in_range : in_range;
+        // the level decode left both as bitmaps (16 levels = one 16-bit word; the arrays are padded)
+        valid = ((const unsigned short*)C.validity)[i0 >> 4] & in_range;
+        starts = ((const unsigned short*)C.row_starts)[i0 >> 4] & in_range;
         if (i0 == 0) starts |= 1;  // the first level opens a row whatever its rep level (write_repeated.go:62-80)
     }
     // block-wide exclusive scan of (row starts, valid)
@@ -2267,7 +2275,7 @@ hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_
                        u32 n_rtiles, RowTile* tiles, ChunkDyn* chunk_dyn) {
     if (n_rchunks == 0) return hipSuccess;
     if (n_rtiles) {
-        hipLaunchKernelGGL((k_rows<false>), dim3(n_rtiles), dim3(256), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles);
+        hipLaunchKernelGGL(k_rows_count, dim3((n_rtiles + 3) / 4), dim3(256), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, n_rtiles, tiles);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_rows_scan, dim3(n_rchunks), dim3(1024), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles, chunk_dyn);

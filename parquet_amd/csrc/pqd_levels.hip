@@ -445,11 +445,12 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     const u32 prefix = s_prefix;
     const u64 my_first = base_v + sv - n_vals;  // local index (within the super-tile's values) of my first run's first value
     const bool counting = R.count_level != ERR_POS;
+    const bool bitmap_only = (R.otile_base & LV_BITMAP_ONLY) != 0;  // repetition levels: which levels are 0, for the row offsets
     LV_STAMP(11);
 
     // Values past NumValues are dropped (fields.go:300,308), but valsFromDefs counts them (fields.go:311): a
     // page whose surplus holds max_def is refused instead of being counted differently.
-    if (counting && (u64)prefix + tot_v > n_out) {
+    if (counting && !bitmap_only && (u64)prefix + tot_v > n_out) {
         bool bad = false;
         if (my_entry != 0xFFFF) {
             u64 o = (u64)prefix + my_first;
@@ -727,7 +728,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
         }
     }
     LV_STAMP(13);
-    if (counting) {
+    if (counting && !bitmap_only) {
         for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
         if (lane == 0) s_wc[wv] = cnt;
         __syncthreads();
