@@ -338,6 +338,26 @@ def test_strings_that_look_like_length_prefixes(ctx):
         H.check_file(buf, ctx)
 
 
+def test_strings_around_quarter_and_tile_boundaries(ctx):
+    """Pass 1 walks a tile in quarters of 512 bytes with rows of their own and hops from quarter to quarter: strings
+    whose 4 + len is a divisor or a near-divisor of 512 / 2048 put every string start on, just before or just behind
+    a quarter or tile boundary; all-zero chars make every position a plausible start of an empty string (chains of
+    4-byte steps that no quarter row catches); lengths of a few hundred bytes land in quarters whose leading
+    positions hold no row at all."""
+    rng = np.random.default_rng(23)
+    cols = [Column("s", N.BYTE_ARRAY, [0])]
+    for ln in (0, 4, 12, 60, 124, 252, 507, 508, 509, 1020, 1021, 2043):
+        for alphabet in ((97, 123), (0, 1), (0, 3)):
+            n = max(40, 30000 // (ln + 4))
+            buf = H.build_file(cols, n, n, max(1, n // 2), rng, str_len=(ln, ln), alphabet=alphabet)
+            H.check_file(buf, ctx)
+    cols = [Column("o", N.BYTE_ARRAY, [1])]
+    for lo, hi in ((500, 520), (250, 260), (120, 135), (2040, 2056)):
+        for alphabet in ((97, 123), (0, 3), (0, 256)):
+            buf = H.build_file(cols, 400, 400, 130, rng, p_null=0.15, str_len=(lo, hi), alphabet=alphabet)
+            H.check_file(buf, ctx)
+
+
 def test_tiny_and_empty_pages(ctx):
     rng = np.random.default_rng(8)
     cols = [Column("a", N.INT32, [1]), Column("s", N.BYTE_ARRAY, [1]), Column("b", N.BOOLEAN, [1]),
