@@ -560,11 +560,10 @@ constexpr u32 STR_TP = STR_A * CH_E_STRINGS;            // (tile, row) pairs of 
 constexpr u32 STR_QP = STR_A * (STR_Q - 1) * STR_E2;    // (tile, quarter, row) pairs
 constexpr u32 STR_PAIRS = STR_TP + STR_QP;
 static_assert(STR_A % 4 == 0, "the probe takes four tiles at a time");
-static_assert(STR_TP == CH_THREADS, "one lane per tile row");
+static_assert(STR_TP <= CH_THREADS, "one lane per tile row");
 static_assert(STR_PAIRS <= 256, "a pair index fits in 8 bits");
 static_assert(STR_QB == 2 * STR_CP_BYTES, "a quarter is two checkpoint blocks");
 static_assert(STR_E2 == 4, "the rows of a quarter are read as one 64-bit word");
-static_assert((STR_A * (STR_Q - 1) * (STR_QPROBE / 8)) % CH_THREADS == 0, "whole sweeps of 8 positions per lane over the quarters");
 static_assert(CH_E_STRINGS % 8 == 0, "a tile's candidate row is read in 16-byte pieces");
 __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                           const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
@@ -722,8 +721,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
     // ---- rows of the quarters: their first STR_E2 candidates among their leading STR_QPROBE positions, 8 lanes each
     constexpr u32 QL = STR_QPROBE / 8;  // lanes per quarter
 #pragma unroll
-    for (u32 it = 0; it < A * (STR_Q - 1) * QL / CH_THREADS; it++) {
-        const u32 pi = it * (CH_THREADS / QL) + lane / QL, j = lane % QL;  // pi = t * (Q - 1) + q - 1
+    for (u32 it = 0; it < (A * (STR_Q - 1) * QL + CH_THREADS - 1) / CH_THREADS; it++) {
+        const u32 pi_raw = it * (CH_THREADS / QL) + lane / QL, j = lane % QL;  // pi = t * (Q - 1) + q - 1
+        const bool pi_ok = pi_raw < A * (STR_Q - 1);
+        const u32 pi = pi_ok ? pi_raw : 0;
         const u32 t = pi / (STR_Q - 1), o = (pi % (STR_Q - 1) + 1) * STR_QB + j * 8;
         const u32* tl = s_tile + t * STR_LDS_WORDS + o / 4;
         const u32 x[3] = {tl[0], tl[1], tl[2]};
@@ -743,6 +744,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
             if (j >= (u32)d) incl += y;
         }
         u32 slot = incl - mine;
+        if (!pi_ok) m = 0;
         while (m && slot < STR_E2) {
             const u32 k = __ffs(m) - 1;
             m &= m - 1;
@@ -811,7 +813,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
     }
     __syncthreads();
     // ---- tile rows: from quarter to quarter to the end of the tile; lane = (tile, row)
-    {
+    if (lane < STR_TP) {
         const u32 t = lane / E;
         const u32 tb = s_tb[t], L = s_len[t];
         const u32 rlim = t < nt ? (tb + CH_T < L ? CH_T : L - tb) : 0;
