@@ -945,20 +945,32 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
             const u32 b = w_tb + (wj + 1) * STR_CP_BYTES;
             end = b < w_lim ? b : w_lim;
         }
-        u32 last_q = q, last_nxt = ERR_POS;
+        // the walk in tile offsets.  A position needs its four length bytes inside the region: up to there the room is
+        // positive and a length is accepted when len < room = L - 3 - position (what str_step_win accepts)
+        const u32 avail = w_len - w_tb, room0 = avail - 3;
+        const u32 rend = end - w_tb, rend4 = avail < 4 ? 0 : rend < room0 ? rend : room0;
+        u32 rel = q == ERR_POS ? ERR_POS : q - w_tb;
+        u32 last_rel = rel, last_nrel = ERR_POS;
         bool walked = false;
-        while (q < end) {
-            const u32 rel = q - w_tb;
+        while (rel < rend4) {
             atomicOr(&bits[rel >> 5], 1u << (rel & 31));
-            u32 nxt;
-            str_step_win(str_len_at(tl, rel), q, w_len, nxt);
-            last_q = q;
-            last_nxt = nxt;
-            q = nxt;
+            const u32 len = str_len_at(tl, rel);
+            last_rel = rel;
+            rel = len < room0 - rel ? rel + 4 + len : ERR_POS;
+            last_nrel = rel;
+            walked = true;
+        }
+        if (rel < rend) {  // a start in the last three bytes of the region: its step fails
+            atomicOr(&bits[rel >> 5], 1u << (rel & 31));
+            last_rel = rel;
+            rel = last_nrel = ERR_POS;
             walked = true;
         }
         // the walker that left the tile (or hit a bad length) holds the tile's last string
-        if (walked && q >= w_lim) { s_last[wt][0] = last_q; s_last[wt][1] = last_nxt; }
+        if (walked && (rel == ERR_POS || w_tb + rel >= w_lim)) {
+            s_last[wt][0] = w_tb + last_rel;
+            s_last[wt][1] = last_nrel == ERR_POS ? ERR_POS : w_tb + last_nrel;
+        }
     }
     __syncthreads();
     u32 n_chars[STR_MG], pad[STR_MG];
