@@ -701,9 +701,36 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
             const u32 v0 = b * 16;
             const u32 lo_v = v0 > mis ? v0 : mis, hi_v = v0 + 16 < v_end ? v0 + 16 : v_end;
             u32x4 v;
+            u32 eq = 0x10000;  // bit k: value k of the block equals count_level; 0x10000: not known yet
+            const u32 cl = R.count_level & 0xFF;
             if (fill) {
                 const u32 f4 = (fill - 1) * 0x01010101u;
                 v = u32x4{f4, f4, f4, f4};
+                eq = fill - 1 == cl ? 0xFFFFu : 0u;
+            } else if (width <= 2 && width) {
+                // the usual widths: the comparison with count_level is made on the packed bits, not on the bytes
+                const u32 bit = (u32)((int)LV_DENSE_BIAS + ((int)v0 - (int)mis) * (int)width);
+                const u32 x = __builtin_amdgcn_alignbit(dense[(bit >> 5) + 1], dense[bit >> 5], bit & 31);  // 16 values
+                if (width == 1) {
+                    // 4 bits -> 4 bytes: n * 0x204081 puts bit i of n at bit 8 i (and others elsewhere)
+                    u32 o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) o[i] = __umul24((x >> (4 * i)) & 15, 0x204081u) & 0x01010101u;
+                    v = u32x4{o[0], o[1], o[2], o[3]};
+                    eq = cl == 1 ? x & 0xFFFFu : cl == 0 ? ~x & 0xFFFFu : 0u;
+                } else {
+                    v = lv_dense16_w<2>(dense, bit);
+                    u32 y = 0;
+                    if (cl < 4) {
+                        const u32 z = x ^ (cl * 0x55555555u);       // a value equals cl where both of its bits are 0
+                        y = ~(z | (z >> 1)) & 0x55555555u;          // bit 2 k: value k equals cl
+                        y = (y | (y >> 1)) & 0x33333333u;           // the even bits, squeezed together
+                        y = (y | (y >> 2)) & 0x0F0F0F0Fu;
+                        y = (y | (y >> 4)) & 0x00FF00FFu;
+                        y = (y | (y >> 8)) & 0xFFFFu;
+                    }
+                    eq = y;
+                }
             } else v = lv_dense16(dense, (u32)((int)LV_DENSE_BIAS + ((int)v0 - (int)mis) * (int)width), width);
             u8* const dst = dbase + v0;
             const u64 acc_lo = v.x | ((u64)v.y << 32), acc_hi = v.z | ((u64)v.w << 32);
@@ -712,7 +739,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
             if (counting) {
                 // bit k: value k of the block equals max_def (fields.go:220-228); bits [k0, k1) are mine
                 const u32 k0 = lo_v - v0, k1 = hi_v - v0;
-                const u32 eq = lv_msb_gather(lv_zero_bytes(acc_lo ^ cl64)) | (lv_msb_gather(lv_zero_bytes(acc_hi ^ cl64)) << 8);
+                if (eq == 0x10000) eq = lv_msb_gather(lv_zero_bytes(acc_lo ^ cl64)) | (lv_msb_gather(lv_zero_bytes(acc_hi ^ cl64)) << 8);
                 const u32 mine = eq & ((0xFFFFu >> (16 - k1)) & (0xFFFFu << k0));
                 cnt += __popc(mine);
                 if (vbits) {
