@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "pqd_device.h"
 #include "pqd_rle.h"
 
@@ -79,6 +81,9 @@ static __device__ __forceinline__ void lv_win_img(const u32* img, u32 r, u32& lo
 // A run header of at most 4 bytes (fewer than 2^27 values or groups) at position p, from the 4 bytes at p: the
 // same answers as rle_step_w32.  n = header bytes (0: the header is longer, nothing else is valid), nxt = next
 // header or ERR_POS, vals = values of the run, bp = bit-packed.
+// TAIL = false: the caller knows that p + 8 <= L, so neither the header nor the value byte of an RLE run nor the first
+// packed byte can lie behind the block end, and the checks for that are left out.
+template <bool TAIL = true>
 static __device__ __forceinline__ void lv_header4(u32 lo, u32 p, u32 L, u32 w, u32& n, u32& nxt, u32& vals, bool& bp) {
     const u32 s = ~lo & 0x80808080u;                                  // the stop bits
     const u32 nb = ((u32)__builtin_ctz(s | 0x80000000u) >> 3) + 1;    // header bytes
@@ -88,8 +93,11 @@ static __device__ __forceinline__ void lv_header4(u32 lo, u32 p, u32 L, u32 w, u
     bp = (h & 1) != 0;
     const u32 prod = w * cnt;                                         // < 2^30
     const u32 bp_nxt = prod >= L - q ? L : q + prod;
-    bool bad = nb > L - p;                                            // header cut off by the block end
-    bad = bad | (bp ? ((w != 0) & (q >= L)) : (bw > L - q));          // io.EOF on the packed bytes / on the value
+    bool bad = false;
+    if (TAIL) {
+        bad = nb > L - p;                                             // header cut off by the block end
+        bad = bad | (bp ? ((w != 0) & (q >= L)) : (bw > L - q));      // io.EOF on the packed bytes / on the value
+    }
     n = s ? nb : 0;
     nxt = bad ? ERR_POS : bp ? bp_nxt : q + bw;
     vals = bad ? 0 : bp ? cnt * 8 : cnt;
@@ -256,26 +264,31 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
 
     LV_STAMP(1);
     // ---- 1. sweep: where the chain of every start leaves my 16 bytes, and the values it passes on the way
+    auto sweep = [&](auto tail_c) {
+        constexpr bool TAIL = decltype(tail_c)::value;  // false: my 16 bytes and 8 more lie inside the block
 #pragma unroll
-    for (int k = (int)LV_SUB - 1; k >= 0; k--) {
-        const u32 p = sub_lo + k;
-        u32 n, nxt, vals;
-        bool bp;
-        lv_header4(lv_win32(w, k), p, L, width, n, nxt, vals, bp);
-        const bool valid = p < L;
-        const bool in = valid & (n != 0) & (nxt < sub_hi) & (nxt < L);  // lands on a later start of mine: its answer is final
-        const u32 mi = (u32)k * LV_PITCH + tid;
-        const u32 mj = in ? (nxt - sub_lo) * LV_PITCH + tid : mi;
-        const u32 t2 = memo0[mj];
-        const u32 d = nxt - sb;
-        u32 enc = nxt == ERR_POS ? LV_ERR : d >= LV_FAR ? LV_FAR : d;
-        if (n == 0) enc = LV_FAR;  // a longer header: parsed with full arithmetic if the true chain comes here
-        if (!valid) enc = LV_ERR;
-        u32 v = enc >= LV_FAR ? LV_VSAT : vals;
-        if (in) v += t2 >> 16;
-        v = v < LV_VSAT ? v : LV_VSAT;
-        memo0[mi] = (in ? t2 & 0xFFFF : enc) | (v << 16);
-    }
+        for (int k = (int)LV_SUB - 1; k >= 0; k--) {
+            const u32 p = sub_lo + k;
+            u32 n, nxt, vals;
+            bool bp;
+            lv_header4<TAIL>(lv_win32(w, k), p, L, width, n, nxt, vals, bp);
+            const bool valid = !TAIL || p < L;
+            const bool in = valid & (n != 0) & (nxt < sub_hi) & (!TAIL || nxt < L);  // lands on a later start of mine: its answer is final
+            const u32 mi = (u32)k * LV_PITCH + tid;
+            const u32 mj = in ? (nxt - sub_lo) * LV_PITCH + tid : mi;
+            const u32 t2 = memo0[mj];
+            const u32 d = nxt - sb;
+            u32 enc = TAIL && nxt == ERR_POS ? LV_ERR : d >= LV_FAR ? LV_FAR : d;
+            if (n == 0) enc = LV_FAR;  // a longer header: parsed with full arithmetic if the true chain comes here
+            if (!valid) enc = LV_ERR;
+            u32 v = enc >= LV_FAR ? LV_VSAT : vals;
+            if (in) v += t2 >> 16;
+            v = v < LV_VSAT ? v : LV_VSAT;
+            memo0[mi] = (in ? t2 & 0xFFFF : enc) | (v << 16);
+        }
+    };
+    if (sub_lo + 24 <= L) sweep(std::false_type{});
+    else sweep(std::true_type{});
     LV_STAMP(2);
     // ---- 2. groups: a wave owns 1 KiB = 4 groups; round s settles the starts of sub-tile s of every group
     // (lane = group * 16 + start).  Only this wave touches these entries: no workgroup barrier between rounds.
