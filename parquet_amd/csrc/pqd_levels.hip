@@ -49,7 +49,7 @@ constexpr u32 LV_VSAT = 0xFFFF;                 // 16-bit value count: this many
 constexpr u32 LV_GROUP = 256;                   // bytes per hop group
 constexpr u32 LV_GSUB = LV_GROUP / LV_SUB;      // sub-tiles per group
 constexpr u32 LV_NGROUPS = LV_T / LV_GROUP;
-constexpr u32 LV_TC = LV_THREADS < 512 ? LV_THREADS : 512;  // tabulated entries of a super-tile: its first LV_TC bytes
+constexpr u32 LV_TC = 128;  // tabulated entries of a super-tile: its first LV_TC bytes (a bit-packed run of 63 groups of width 2 reaches 127 bytes into the next super-tile)
 constexpr u32 LV_DENSE_BITS = 65536;            // bits of the dense level stream per expand window
 constexpr u32 LV_DENSE_BIAS = 128;              // the stream starts at this bit: a block may begin up to 15 values before the window
 constexpr u32 LV_DENSE_WORDS = LV_DENSE_BIAS / 32 + LV_DENSE_BITS / 32 + 6;
