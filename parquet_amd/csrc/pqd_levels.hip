@@ -546,41 +546,20 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
                     accn -= 32;
                 }
             };
-            for (;;) {
-                const bool act = q < sub_hi && q < L;
-                if (!__any(act)) break;
-                u32 b0 = 0, b1 = 0, pay = 0, nxt = ERR_POS, vals = 0;
+            // A run that is not of the usual kind (below) is put off until the thread has gone through its sub-tile, so
+            // that the lanes of a wave take the long way together: `slow` writes one such run of every lane that has one.
+            auto slow = [&](bool on, u32 qs, u64 ras) {
+                u32 b0 = 0, b1 = 0, pay = 0;
                 u64 pat = 0, sbit0 = 0;
                 bool bp = false, is_long = false;
-                if (act) {
-                    u32 info, pay32, pay_bits;
+                if (on) {
+                    u32 nxt, vals, info, pay32, pay_bits;
                     u64 pay64;
                     bool pay_ok;
-                    lv_run(img, q - sb, q, L, width, nxt, vals, info, pay32, pay_ok, &pay64, &pay_bits);
-                    const u64 rb = ra + vals;
-                    // the usual run: short, in the window as a whole, its bits at hand (an RLE value, or packed bytes
-                    // that came with the header): two appends at most, no loops
-                    const u32 nb_all = vals <= 64 ? __umul24(vals, width) : 0xFFFFFFFFu;
-                    const bool quick = vals && ra >= W0 && rb <= W1 && nb_all <= ((info & 1) ? pay_bits : 64u) &&
-                                       !(ra == W0 && rb == W1);
-                    if (quick) {
-                        const u32 qb0 = LV_DENSE_BIAS + __umul24((u32)ra - W0, width);
-                        u64 bits;
-                        if (info & 1) bits = pay64;
-                        else {
-                            const u32 v = info >> 1;
-                            if (rep_mul) { const u32 p32 = v * (u32)rep_mul; bits = p32 | ((u64)p32 << 32); }  // width 1, 2, 4 or 8
-                            else { bits = v; for (u32 sft = width; sft < 64; sft <<= 1) bits |= bits << sft; }
-                        }
-                        if (nb_all < 64) bits &= (1ull << nb_all) - 1;
-                        if (bits) {  // zeros are there already
-                            acc_seek(qb0);
-                            const u32 n1 = nb_all < 32 ? nb_all : 32;
-                            append((u32)bits, n1);
-                            if (nb_all > 32) append((u32)(bits >> 32), nb_all - 32);
-                        }
-                    } else if (vals && ra < W1 && rb > W0) {
-                        const u32 s = ra > W0 ? (u32)ra : W0, t = rb < W1 ? (u32)rb : W1;
+                    lv_run(img, qs - sb, qs, L, width, nxt, vals, info, pay32, pay_ok, &pay64, &pay_bits);
+                    const u64 rb = ras + vals;
+                    if (vals && ras < W1 && rb > W0) {
+                        const u32 s = ras > W0 ? (u32)ras : W0, t = rb < W1 ? (u32)rb : W1;
                         b0 = LV_DENSE_BIAS + (s - W0) * width;
                         b1 = LV_DENSE_BIAS + (t - W0) * width;
                         const u32 nbits = b1 - b0;
@@ -594,10 +573,10 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
                             live = v != 0;  // zeros are there already
                         } else {
                             pay = info >> 1;
-                            sbit0 = (u64)(s - ra) * width;
+                            sbit0 = (u64)(s - ras) * width;
                         }
                         u32 bits_left = nbits;  // what this thread still has to put into the stream itself
-                        if (bp && s == ra && t == rb && nbits > 64) {
+                        if (bp && s == ras && t == rb && nbits > 64) {
                             // A bit-packed run that lies in the window as a whole is its packed bytes, copied.  This thread
                             // copies the ones in its own 16 bytes; the threads of the sub-tiles behind it copy theirs (7a',
                             // told where through `anch`: stream bit | bytes << 17 | first byte << 22); what lies behind the
@@ -640,7 +619,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
                                     rem -= take;
                                     if (odd_w) { ph += 32 % width; if (ph >= width) ph -= width; }
                                 }
-                            } else if (bits_left <= 32 && pay_ok && s == ra && bits_left == nbits) {
+                            } else if (bits_left <= 32 && pay_ok && s == ras && bits_left == nbits) {
                                 append(pay32 & (0xFFFFFFFFu >> (32 - bits_left)), bits_left);  // the packed bits are in my registers
                             } else {
                                 u64 sbit = sbit0;
@@ -659,7 +638,6 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
                             }
                         }
                     }
-                    ra = rb;
                 }
                 u64 lm = __ballot(is_long);
                 while (lm) {
@@ -675,8 +653,54 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
                         if (x) atomicOr(&dense[jw], x);
                     }
                 }
+            };
+            u32 dq0 = ERR_POS, dq1 = ERR_POS;  // the runs put off
+            u64 dra0 = 0, dra1 = 0;
+            for (;;) {
+                const bool act = q < sub_hi && q < L;
+                if (!__any(act)) break;
+                u32 nxt = ERR_POS;
+                bool now = false;  // a third run put off: written at once
+                const u64 ra_run = ra;
+                if (act) {
+                    u32 vals, info, pay32, pay_bits;
+                    u64 pay64;
+                    bool pay_ok;
+                    lv_run(img, q - sb, q, L, width, nxt, vals, info, pay32, pay_ok, &pay64, &pay_bits);
+                    const u64 rb = ra + vals;
+                    // the usual run: short, in the window as a whole, its bits at hand (an RLE value, or packed bytes
+                    // that came with the header): two appends at most, no loops
+                    const u32 nb_all = vals <= 64 ? __umul24(vals, width) : 0xFFFFFFFFu;
+                    const bool quick = vals && ra >= W0 && rb <= W1 && nb_all <= ((info & 1) ? pay_bits : 64u) &&
+                                       !(ra == W0 && rb == W1);
+                    if (quick) {
+                        const u32 qb0 = LV_DENSE_BIAS + __umul24((u32)ra - W0, width);
+                        u64 bits;
+                        if (info & 1) bits = pay64;
+                        else {
+                            const u32 v = info >> 1;
+                            if (rep_mul) { const u32 p32 = v * (u32)rep_mul; bits = p32 | ((u64)p32 << 32); }  // width 1, 2, 4 or 8
+                            else { bits = v; for (u32 sft = width; sft < 64; sft <<= 1) bits |= bits << sft; }
+                        }
+                        if (nb_all < 64) bits &= (1ull << nb_all) - 1;
+                        if (bits) {  // zeros are there already
+                            acc_seek(qb0);
+                            const u32 n1 = nb_all < 32 ? nb_all : 32;
+                            append((u32)bits, n1);
+                            if (nb_all > 32) append((u32)(bits >> 32), nb_all - 32);
+                        }
+                    } else if (vals && ra < W1 && rb > W0) {
+                        if (dq0 == ERR_POS) { dq0 = q; dra0 = ra; }
+                        else if (dq1 == ERR_POS) { dq1 = q; dra1 = ra; }
+                        else now = true;
+                    }
+                    ra = rb;
+                }
+                if (__any(now)) slow(now, q, ra_run);
                 if (act) q = nxt;
             }
+            if (__any(dq0 != ERR_POS)) slow(dq0 != ERR_POS, dq0, dra0);
+            if (__any(dq1 != ERR_POS)) slow(dq1 != ERR_POS, dq1, dra1);
             acc_flush();
             // ---- 7a'. packed bytes of runs that started in an earlier sub-tile: every thread copies its own
             __syncthreads();
