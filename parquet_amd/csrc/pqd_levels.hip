@@ -699,9 +699,11 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
                 if (__any(now)) slow(now, q, ra_run);
                 if (act) q = nxt;
             }
+            LV_STAMP(14);
             if (__any(dq0 != ERR_POS)) slow(dq0 != ERR_POS, dq0, dra0);
             if (__any(dq1 != ERR_POS)) slow(dq1 != ERR_POS, dq1, dra1);
             acc_flush();
+            LV_STAMP(15);
             // ---- 7a'. packed bytes of runs that started in an earlier sub-tile: every thread copies its own
             __syncthreads();
             const u32 an = s_anch ? anch[tid] : 0;  // s_anch is the same for all threads: no anchors, no second barrier

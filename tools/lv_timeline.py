@@ -48,6 +48,9 @@ def main():
             continue
         d = us[valid, i] - us[valid, i - 1]
         print("%-14s %9.2f %9.2f %9.2f | %9.1f %9.1f" % (NAMES[i], np.median(d), np.percentile(d, 90), d.max(), us[valid, i].min(), us[valid, i].max()))
+    for nm, i, j in (("win zero+main loop", 14, 11), ("slow runs", 15, 14), ("7a' + barriers", 12, 15)):
+        d = us[:, i] - us[:, j]
+        print("%-20s %9.2f %9.2f %9.2f" % (nm, np.median(d), np.percentile(d, 90), d.max()))
     print("start times: median %.1f p90 %.1f max %.1f" % (np.median(us[:, 0]), np.percentile(us[:, 0], 90), us[:, 0].max()))
     plan.close()
     ctx.close()
