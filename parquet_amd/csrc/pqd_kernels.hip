@@ -527,6 +527,15 @@ static __device__ __forceinline__ u32 str_len_at(const u32* s_tile, u32 rel) {
     return __builtin_amdgcn_alignbit(s_tile[d + 1], s_tile[d], (rel & 3) * 8);
 }
 
+// A position is a candidate (a plausible string start) when its four bytes are a length that fits into the rest of the
+// region (r = L - 3 - position) and is below STR_CAND_MAX.  The second condition is what keeps contents with zero
+// bytes (UTF-16 text: a zero behind every letter) from looking like lengths in a page of many megabytes.  A true start
+// that it rejects, a string of 1 MiB or more, is an entry that no table holds: the hop kernels step over that one
+// string themselves (about a microsecond each, one after the other per page; with a bound of 64 KiB a page of 118 MB of
+// strings of 60-200 KB took 1.14 ms instead of 0.28 ms).
+constexpr u32 STR_CAND_MAX = 1u << 20;
+static __device__ __forceinline__ u32 str_cand_room(int r) { return r > 0 ? ((u32)r < STR_CAND_MAX ? (u32)r : STR_CAND_MAX) : 0; }
+
 // Pass 1: STR_A tiles per wave, CH_E_STRINGS rows per tile.
 //   candidates  the positions of a tile whose four bytes are a length that fits in the page.  Every true string
 //               start is one; in text hardly anything else is (the two positions in front of a true start, whose
@@ -649,8 +658,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
     const bool have_next = group_whole(iter + 1);
     if (have_next) prefetch(iter + 1);
     __syncthreads();
-    // ---- candidates; a position p is one when len < max(L - 3 - p, 0), which is what str_step_win accepts (and is
-    // false for p >= L).  First the leading STR_PROBE positions of four tiles at a time, 8 positions per lane.
+    // ---- candidates; a position p is one when len < min(max(L - 3 - p, 0), STR_CAND_MAX); str_step_win accepts every one
+    // of them (and no p >= L is one).  First the leading STR_PROBE positions of four tiles at a time, 8 positions per lane.
 #pragma unroll
     for (u32 it = 0; it < A / 4; it++) {
         const u32 t = it * 4 + (lane >> 4), j = lane & 15, o = j * 8;
@@ -662,7 +671,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
         for (u32 k = 0; k < 8; k++) {
             const u32 len = (k & 3) ? __builtin_amdgcn_alignbit(x[k / 4 + 1], x[k / 4], (k & 3) * 8) : x[k / 4];
             const int r = room - (int)k;
-            m |= (u32)(len < (u32)(r > 0 ? r : 0)) << k;
+            m |= (u32)(len < str_cand_room(r)) << k;
         }
         const u32 mine = __popc(m);
         u32 incl = mine;
@@ -698,7 +707,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
                 for (u32 k = 0; k < 8; k++) {
                     const u32 len = (k & 3) ? __builtin_amdgcn_alignbit(x[k / 4 + 1], x[k / 4], (k & 3) * 8) : x[k / 4];
                     const int r = room - (int)k;
-                    m |= (u32)(len < (u32)(r > 0 ? r : 0)) << k;
+                    m |= (u32)(len < str_cand_room(r)) << k;
                 }
             }
             const u32 mine = __popc(m);
@@ -734,7 +743,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
         for (u32 k = 0; k < 8; k++) {
             const u32 len = (k & 3) ? __builtin_amdgcn_alignbit(x[k / 4 + 1], x[k / 4], (k & 3) * 8) : x[k / 4];
             const int r = room - (int)k;
-            m |= (u32)(len < (u32)(r > 0 ? r : 0)) << k;
+            m |= (u32)(len < str_cand_room(r)) << k;
         }
         const u32 mine = __popc(m);
         u32 incl = mine;

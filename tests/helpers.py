@@ -77,7 +77,11 @@ def random_strings(n, rng, lo=0, hi=24, alphabet=(0, 256)):
     lens = rng.integers(lo, hi + 1, n)
     offsets = np.zeros(n + 1, np.int32)
     np.cumsum(lens, out=offsets[1:])
-    chars = rng.integers(alphabet[0], alphabet[1], int(offsets[-1]), dtype=np.uint8)
+    if alphabet == "utf16":  # letters with a zero byte behind each: most positions then look like a length prefix
+        chars = rng.integers(97, 123, int(offsets[-1]), dtype=np.uint8)
+        chars[1::2] = 0
+    else:
+        chars = rng.integers(alphabet[0], alphabet[1], int(offsets[-1]), dtype=np.uint8)
     return chars, offsets
 
 

@@ -358,6 +358,40 @@ def test_strings_around_quarter_and_tile_boundaries(ctx):
             H.check_file(buf, ctx)
 
 
+def test_strings_with_a_zero_behind_every_letter_in_a_large_page(ctx):
+    """UTF-16-like chars in one page of 16 MB: four bytes `a 0 b 0` read as a length of a few megabytes, which fits
+    into the rest of such a page; without an upper bound on the lengths a candidate may have, half of all positions
+    are candidates and no tile's rows hold its true entry."""
+    rng = np.random.default_rng(29)
+    cols = [Column("o", N.BYTE_ARRAY, [1])]
+    n = 520000
+    buf = H.build_file(cols, n, n, n, rng, p_null=0.1, str_len=(8, 52), alphabet="utf16")
+    o, g = H.check_file(buf, ctx)
+    assert len(g[(0, "o")]["chars"]) > 12 << 20
+
+
+def test_strings_longer_than_the_candidate_bound(ctx):
+    """Strings of 1 MiB and more are true starts that pass 1 does not take for candidates: the hop kernels find no
+    table row for them and step over them one by one.  Short strings between them, and one as the page's last value."""
+    rng = np.random.default_rng(31)
+    cols = [Column("s", N.BYTE_ARRAY, [0])]
+    lens = []
+    for big in ((1 << 20) - 1, 1 << 20, (1 << 20) + 1, 1500000, 2200000):
+        lens += [int(x) for x in rng.integers(0, 40, int(rng.integers(1, 200)))] + [big]
+    lens += [5, 0, 1 << 20]
+    offs = np.zeros(len(lens) + 1, np.int32)
+    np.cumsum(lens, out=offs[1:])
+    chars = rng.integers(0, 256, int(offs[-1]), dtype=np.uint8)
+    w = ParquetWriter(cols, stats=False)
+    w.begin_row_group()
+    w.write_page(0, chars, offsets=offs)
+    w.end_row_group(len(lens))
+    buf = w.finish()
+    w.close()
+    o, g = H.check_file(buf, ctx)
+    assert bytes(g[(0, "s")]["chars"]) == chars.tobytes()
+
+
 def test_tiny_and_empty_pages(ctx):
     rng = np.random.default_rng(8)
     cols = [Column("a", N.INT32, [1]), Column("s", N.BYTE_ARRAY, [1]), Column("b", N.BOOLEAN, [1]),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Decode time of one optional string column as a function of the string length (runs on the GPU box).
-usage: python tools/str_len_bench.py [rows] [lo:hi ...]      (ALPHABET=lo:hi in the environment sets the byte range of the chars;
-bytes near zero make most positions look like string lengths)"""
+usage: python tools/str_len_bench.py [rows] [lo:hi ...]      (ALPHABET=lo:hi in the environment sets the byte range of the chars,
+ALPHABET=utf16 puts a zero byte behind every letter, PAGES=n cuts the chunk into n pages; bytes near zero make most positions look like string lengths)"""
 import os
 import sys
 import time
@@ -20,12 +20,14 @@ from parquet_amd.writer import Column  # noqa: E402
 def main():
     rows = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
     ranges = [tuple(int(x) for x in a.split(":")) for a in sys.argv[2:]] or [(8, 32), (40, 60), (61, 100), (100, 400), (1000, 3000)]
-    alphabet = tuple(int(x) for x in os.environ.get("ALPHABET", "97:123").split(":"))
+    alphabet = os.environ.get("ALPHABET", "97:123")
+    alphabet = alphabet if alphabet == "utf16" else tuple(int(x) for x in alphabet.split(":"))
+    pages = int(os.environ.get("PAGES", "4"))  # pages of the column chunk
     ctx = R.Context(0)
     for lo, hi in ranges:
         rng = np.random.default_rng(lo)
         n = max(1000, int(rows * 20 / ((lo + hi) / 2)))  # about the same number of bytes for every range
-        buf = H.build_file([Column("s", N.BYTE_ARRAY, [1])], n, n, n // 4, rng, p_null=0.1, str_len=(lo, hi), alphabet=alphabet)
+        buf = H.build_file([Column("s", N.BYTE_ARRAY, [1])], n, n, (n + pages - 1) // pages, rng, p_null=0.1, str_len=(lo, hi), alphabet=alphabet)
         pf = R.ParquetFile(buf)
         chunks, nc, pgs, npg = pf.descriptors(0, pf.num_row_groups)
         plan = R.Plan(ctx, chunks, nc, pgs, npg, pf.address, pf.size)
