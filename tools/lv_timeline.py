@@ -23,7 +23,8 @@ NAMES = ["start", "loaded", "sweep", "groups", "exits", "entry known", "publishe
 def main():
     workload = sys.argv[1] if len(sys.argv) > 1 else "optint"
     pages = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-    buf, _ = bench.build_file(workload, [0, 1], pages, 1_000_000)
+    rows_per_page = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+    buf, _ = bench.build_file(workload, [0, 1], pages, rows_per_page)
     pf = R.ParquetFile(buf)
     ctx = R.Context(0)
     chunks, nc, pgs, npg = pf.descriptors(0, pf.num_row_groups)
