@@ -154,7 +154,7 @@ hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Re
 constexpr u32 LV_T = PQD_LV_TILE_BYTES;   // chain bytes per super-tile in this translation unit
 constexpr u32 LV_THREADS = LV_T / 16;     // one 16-byte sub-tile per thread
 constexpr u32 LV_T_SMALL_BATCH = 8192, LV_T_LARGE_BATCH = 4096;
-constexpr u32 LV_LARGE_BATCH_TILES = 1536;  // a batch of more 8 KiB super-tiles than this takes the 4 KiB build (two rounds of resident workgroups)
+constexpr u32 LV_LARGE_BATCH_TILES = 1000;  // a batch of more 8 KiB super-tiles than this takes the 4 KiB build (optional int32, 10 % nulls: 608 super-tiles 71 vs 73 us, 1216: 104 vs 98 us, 2432: 177 vs 146 us)
 constexpr u32 LV_SUB = LV_T / LV_THREADS;
 constexpr u32 LV_SPIN_MAX = 1u << 22;  // polls of a granule before a workgroup gives up (safety net, never reached)
 struct LvTile { u32 region, index; };  // launch order: super-tile `index` of `region`; predecessors come first

@@ -78,7 +78,7 @@ def test_long_runs_across_super_tiles(ctx, small_tiles):
 
 
 def test_a_large_batch_selects_the_small_tiles_by_itself(ctx):
-    """More than 1536 super-tiles of 8 KiB: 112 pages of 1M optional levels (128 KB of level bytes each)."""
+    """More super-tiles of 8 KiB than the planner gives to the 8 KiB build (1000): 112 pages of 1M optional levels (128 KB of level bytes each)."""
     buf, ex = bench.build_file("optint", list(range(7)), 16, 1_000_000)
     pf = R.ParquetFile(buf)
     chunks, nc, pgs, npg = pf.descriptors(0, pf.num_row_groups)
