@@ -242,8 +242,8 @@ typedef struct {
 /* Host only: reads the uvarint preamble of every block.  PQD_E_CORRUPT as snappy.ErrCorrupt. */
 int pqd_snappy_sizes(const void* src_host, size_t src_len, pqd_snappy_block* blocks, size_t n);
 /* Decodes n blocks from device memory to device memory and waits for them.  PQD_E_CORRUPT where
- * snappy.Decode returns ErrCorrupt; PQD_E_UNSUPPORTED for a stream whose copies reach across a 64 KiB
- * boundary of the output (no encoder the reference links produces one). */
+ * snappy.Decode returns ErrCorrupt.  Copies may reach back as far as the format allows (any offset up to
+ * the bytes written so far, all three copy tags), as in snappy.Decode. */
 int pqd_snappy_decode(pqd_ctx* ctx, const pqd_snappy_block* blocks, size_t n, const void* src_device, size_t src_len,
                       void* dst_device, size_t dst_len);
 /* Fills rep_bytes / def_bytes of pages whose payload exists only on the device (decoded pages): the

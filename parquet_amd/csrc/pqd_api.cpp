@@ -1094,6 +1094,8 @@ int pqd_snappy_decode(pqd_ctx* ctx, const pqd_snappy_block* blocks, size_t n, co
     const size_t o_otf = ap.take(((size_t)n_otiles + 1) * 4);
     const size_t ff_end = ap.total;
     const size_t o_status = ap.take(16);
+    const size_t o_done = ap.take(((size_t)n_otiles + 1) * 4);  // a flag per output tile and the ticket counter
+    const size_t zero_end = ap.total;
     u8* A = nullptr;
     hipError_t e = hipMalloc((void**)&A, ap.total);
     if (e != hipSuccess) return fail(ctx, PQD_E_NOMEM, "hipMalloc of the snappy scratch failed", e);
@@ -1101,7 +1103,7 @@ int pqd_snappy_decode(pqd_ctx* ctx, const pqd_snappy_block* blocks, size_t n, co
     const ChainArgs ca{(Region*)(A + o_reg), (u32*)(A + o_tp), (u32*)(A + o_gp), (u32)n, n_tiles, n_groups, (ExitRec*)(A + o_exit),
                        (ExitRec*)(A + o_gexit), (TileEntry*)(A + o_te), (TileEntry*)(A + o_ge), (RegionTotal*)(A + o_tot)};
     HIP_TRY(ctx, hipMemsetAsync(A + o_ff, 0xFF, ff_end - o_ff, st));
-    HIP_TRY(ctx, hipMemsetAsync(A + o_status, 0, 16, st));
+    HIP_TRY(ctx, hipMemsetAsync(A + o_status, 0, zero_end - o_status, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_reg, regions.data(), n * sizeof(Region), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_tp, tile_prefix.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(A + o_gp, group_prefix.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
@@ -1110,14 +1112,13 @@ int pqd_snappy_decode(pqd_ctx* ctx, const pqd_snappy_block* blocks, size_t n, co
     HIP_TRY(ctx, launch_chain(st, KIND_SNAPPY, src, ca, (RunRec*)(A + o_runs), (u32*)(A + o_otf), nullptr, (int*)(A + o_status), 0));
     HIP_TRY(ctx, launch_chain(st, KIND_SNAPPY, src, ca, (RunRec*)(A + o_runs), (u32*)(A + o_otf), nullptr, (int*)(A + o_status), 1));
     HIP_TRY(ctx, launch_snappy_tiles(st, src, (Region*)(A + o_reg), (u32*)(A + o_otr), (u32)n_otiles, (RunRec*)(A + o_runs),
-                                     (u32*)(A + o_otf), (RegionTotal*)(A + o_tot), (int*)(A + o_status)));
+                                     (u32*)(A + o_otf), (RegionTotal*)(A + o_tot), (int*)(A + o_status), (u32*)(A + o_done)));
     int status[4] = {0, 0, 0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(status, A + o_status, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (status[0]) {
         char b[160];
-        snprintf(b, sizeof b, "snappy decode failed: device status %d at block %d%s", status[0], status[1],
-                 status[0] == ST_UNSUPPORTED ? " (a copy reaches across a 64 KiB output block)" : "");
+        snprintf(b, sizeof b, "snappy decode failed: device status %d at block %d", status[0], status[1]);
         ctx->err = b;
         return map_status(status[0]);
     }

@@ -196,9 +196,11 @@ hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_
                        u32 n_rtiles, RowTile* tiles, ChunkDyn* chunk_dyn);
 
 // snappy: decode tiles of SN_T output bytes from the element records (otile_region / otile_first_run have one
-// spare entry each); every Region.out must be 16-byte aligned
+// spare entry each); every Region.out must be 16-byte aligned; tile_done: n_otiles + 1 words, all zero (one flag
+// per tile and the ticket counter)
 hipError_t launch_snappy_tiles(hipStream_t st, const u8* src, const Region* regions, const u32* otile_region, u32 n_otiles,
-                               const RunRec* run_tbl, const u32* otile_first_run, const RegionTotal* totals, int* status);
+                               const RunRec* run_tbl, const u32* otile_first_run, const RegionTotal* totals, int* status,
+                               u32* tile_done);
 // sizes[2*i], sizes[2*i+1] = rep / def level block bytes of page i (PageRec.val_src_off / val_len = its whole payload)
 hipError_t launch_level_block_sizes(hipStream_t st, const u8* src, const PageRec* pages, const ChunkRec* chunks, u32 n_pages,
                                     int* sizes);

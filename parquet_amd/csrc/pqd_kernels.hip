@@ -1759,8 +1759,11 @@ __global__ void k_str_check(const Region* __restrict__ regions, u32 n_regions, c
 //      barriers.  A copy that overlaps its own output (offset < length) repeats its pattern as the
 //      format says;
 //   3. the tile leaves as aligned 16-byte stores.
-// The usual encoders (golang/snappy, C++ snappy) compress 64 KiB blocks independently, so no copy reaches
-// across a tile boundary; a stream that does is reported as unsupported rather than decoded wrongly.
+// The usual encoders (golang/snappy, C++ snappy) compress 64 KiB blocks independently, so their copies stay
+// inside a tile.  snappy.Decode takes any offset up to the bytes written so far, so a copy may also reach into
+// (or continue from) an earlier tile: those source bytes are read from the earlier tile's output in memory once
+// that tile has raised its flag in `tile_done`.  Workgroups take their tile from a ticket counter, so the tiles a
+// workgroup waits for belong to workgroups that already run.
 // d < offset (a copy reaching before the start of the output) is ErrCorrupt.
 // =====================================================================================
 constexpr u32 SN_THREADS = 256;  // 4 waves per 64 KiB tile (8 are 11 % faster on text and 12 % slower on long runs,
@@ -1768,12 +1771,16 @@ constexpr u32 SN_THREADS = 256;  // 4 waves per 64 KiB tile (8 are 11 % faster o
 __global__ __launch_bounds__(SN_THREADS) void k_snappy_tiles(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                       const u32* __restrict__ otile_region, const RunRec* __restrict__ run_tbl,
                                                       const u32* __restrict__ otile_first_run,
-                                                      const RegionTotal* __restrict__ totals, int* __restrict__ status) {
+                                                      const RegionTotal* __restrict__ totals, int* __restrict__ status,
+                                                      u32* __restrict__ tile_done, u32* __restrict__ ticket, u32 n_otiles) {
     __shared__ __attribute__((aligned(16))) u8 s_o[SN_T];
     __shared__ u32 s_fin[SN_T / 32];  // bit i: output byte i of the tile is final
-    __shared__ u32 s_next;
+    __shared__ u32 s_next, s_ticket;
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 ot = blockIdx.x;
+    if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const u32 ot = s_ticket;
+    if (ot >= n_otiles) return;
     const u32 ri = otile_region[ot];
     u32 first = otile_first_run[ot];
     const u32 nf = otile_first_run[ot + 1];
@@ -1901,35 +1908,62 @@ __global__ __launch_bounds__(SN_THREADS) void k_snappy_tiles(const u8* __restric
         if (w0 >= last) break;
         const u32 e = w0 + lane;
         const u32 INF = 0xFFFFFFFFu;
-        bool pending = false;
-        u32 o = INF, oe = INF, len = 0, off = 0;  // every lane holds its element's output range, literals too
+        bool pending = false, far = false;
+        u32 o = INF, oe = INF, off = 0;  // every lane holds its element's output range, literals too
+        u32 co = 0, len = 0;             // a copy's bytes inside this tile: [co, co + len) of the block's output
         if (e < last) {
             const RunRec rr = runs[e];
             o = rr.out_off;
             oe = e + 1 < T.cnt ? runs[e + 1].out_off : n_out;
             if (rr.info & 1) {
-                len = oe - o;
                 off = rr.info >> 1;
-                pending = true;
-                int bad = 0;
-                if (off > o) bad = ST_CORRUPT;                                          // d < offset
-                else if (o < B || o + len > t_hi || o - off < B) bad = ST_UNSUPPORTED;  // reaches across tiles
-                if (bad) {
+                co = o > B ? o : B;
+                const u32 ce = oe < t_hi ? oe : t_hi;
+                len = ce > co ? ce - co : 0;
+                pending = len != 0;
+                if (off > o || off == 0) {                                              // d < offset, offset 0
                     // its bytes count as final all the same, so that nothing waits for them forever
-                    set_status(status, bad, ri);
-                    const u32 a = (o > B ? o : B), b = (o + len < t_hi ? o + len : t_hi);
-                    if (b > a) mark_range(a - B, b - B);
+                    set_status(status, ST_CORRUPT, ri);
+                    if (len) mark_range(co - B, co - B + len);
                     pending = false;
+                } else far = pending && co - off < B;  // the first source bytes lie in an earlier tile
+            }
+        }
+        // Copies whose source begins in an earlier tile, one after the other with the whole wave: wait for the
+        // tiles that hold the bytes, fetch them from the block's output in memory, and leave what remains (a
+        // source inside this tile) to the usual way below.
+        for (u64 fm = __ballot(far); fm; fm &= fm - 1) {
+            const int l = __ffsll((unsigned long long)fm) - 1;
+            const u32 f_co = __shfl(co, l), f_len = __shfl(len, l), f_off = __shfl(off, l);
+            const u32 f_n = f_len < B + f_off - f_co ? f_len : B + f_off - f_co;  // bytes whose source lies before B
+            const u32 q0 = (f_co - f_off) / SN_T, q1 = (f_co - f_off + f_n - 1) / SN_T;
+            bool ok = true;
+            for (u32 q = q0 + lane; q <= q1; q += 64) {
+                u32 spins = 0;
+                while (!__hip_atomic_load(tile_done + R.otile_base + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (++spins > SN_SPIN_MAX) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(4);
                 }
+            }
+            if (!__all(ok)) { if (lane == 0) set_status(status, ST_INTERNAL, ri); }
+            __threadfence();  // the other tile's bytes were written before its flag
+            const u8* const g = R.out + (f_co - f_off);
+            for (u32 k = lane; k < f_n; k += 64) s_o[f_co - B + k] = g[k];
+            __threadfence_block();  // bytes before bits
+            mark_wave(f_co - B, f_co - B + f_n);
+            if ((int)lane == l) {
+                co += f_n;
+                len -= f_n;
+                pending = len != 0;
             }
         }
         // source bytes [sa, sb) and own bytes [da, db), tile relative
-        const u32 da = o - B, db = da + len, sa = da - off, sb = sa + (len < off ? len : off);
+        const u32 da = co - B, db = da + len, sa = da - off, sb = sa + (len < off ? len : off);
         // The part of the source that lies inside this chunk's own output depends on copies of this wave only:
         // the outputs of the chunk's elements are consecutive, so the lanes whose output overlaps my source are a
         // contiguous range (two binary searches over the lanes), and waiting for them is a ballot, not a trip
         // through the bitmap.  The part in front of the chunk waits for the bitmap as before.
-        const u32 sA = o - off, sB = sA + (len < off ? len : off);
+        const u32 sA = co - off, sB = sA + (len < off ? len : off);
         u32 c_lo = 0, c_hi = 0;  // lanes with oe <= sA / lanes with o < sB
         {
             const u32 v = __shfl(oe, 63), v2 = __shfl(o, 63);
@@ -1944,7 +1978,9 @@ __global__ __launch_bounds__(SN_THREADS) void k_snappy_tiles(const u8* __restric
         }
         u64 wait = 0;
         if (pending && c_hi > c_lo) wait = (c_hi >= 64 ? ~0ull : (1ull << c_hi) - 1) & ~((1ull << c_lo) - 1);
-        const u32 chunk_lo = __shfl(o, 0) - B;              // tile offset where this chunk's output starts
+        wait &= ~(1ull << lane);  // what is left of a copy that began with bytes from an earlier tile may copy those
+        const u32 chunk_o = __shfl(o, 0);
+        const u32 chunk_lo = chunk_o > B ? chunk_o - B : 0;  // tile offset where this chunk's output starts
         const u32 xb = sb < chunk_lo ? sb : chunk_lo;       // [sa, xb): the source in front of the chunk
         bool cross = pending && sa < xb;
         u32 spins = 0;
@@ -2001,6 +2037,10 @@ __global__ __launch_bounds__(SN_THREADS) void k_snappy_tiles(const u8* __restric
         if (i + 16 <= n) *(u32x4*)(dst + i) = *(const u32x4*)(s_o + i);
         else for (u32 k = i; k < n; k++) dst[k] = s_o[k];
     }
+    // the tile's bytes are in memory: later tiles of the block may read them
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(tile_done + ot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Level block sizes of pages whose payload only exists on the device (decompressed pages): the int32
@@ -2311,10 +2351,12 @@ hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_
 }
 
 hipError_t launch_snappy_tiles(hipStream_t st, const u8* src, const Region* regions, const u32* otile_region, u32 n_otiles,
-                               const RunRec* run_tbl, const u32* otile_first_run, const RegionTotal* totals, int* status) {
+                               const RunRec* run_tbl, const u32* otile_first_run, const RegionTotal* totals, int* status,
+                               u32* tile_done) {
     if (n_otiles == 0) return hipSuccess;
+    // tile_done: n_otiles flags and the ticket counter behind them, all zero
     hipLaunchKernelGGL(k_snappy_tiles, dim3(n_otiles), dim3(SN_THREADS), 0, st, src, regions, otile_region, run_tbl, otile_first_run,
-                       totals, status);
+                       totals, status, tile_done, tile_done + n_otiles, n_otiles);
     LAUNCH_CHECK();
     return hipSuccess;
 }

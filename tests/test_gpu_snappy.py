@@ -140,16 +140,96 @@ def test_bad_copy_with_dependents_is_an_error_not_a_hang(ctx):
     assert e.value.code == N.E_CORRUPT
 
 
-def test_copy_across_64k_output_blocks_is_reported_unsupported(ctx):
-    """Valid snappy that no block-wise encoder writes: a copy whose source lies in the previous 64 KiB of
-    output.  The oracle (like snappy.Decode) reads it; the device decoder says so instead of guessing."""
+def _lit(x):
+    n = len(x) - 1
+    if n < 60:
+        return bytes([n << 2]) + x
+    if n < 256:
+        return bytes([60 << 2, n]) + x
+    if n < 65536:
+        return bytes([61 << 2]) + n.to_bytes(2, "little") + x
+    return bytes([62 << 2]) + n.to_bytes(3, "little") + x
+
+
+def _copy(length, offset, kind=None):
+    """One copy element; kind 1 / 2 / 4 = bytes of the offset field (1: 11-bit offset, lengths 4..11)."""
+    if kind is None:
+        kind = 1 if (4 <= length <= 11 and offset < 2048) else 2 if offset < 65536 else 4
+    if kind == 1:
+        return bytes([((offset >> 8) << 5) | ((length - 4) << 2) | 1, offset & 0xFF])
+    if kind == 2:
+        return bytes([((length - 1) << 2) | 2]) + offset.to_bytes(2, "little")
+    return bytes([((length - 1) << 2) | 3]) + offset.to_bytes(4, "little")
+
+
+def _apply(out, length, offset):
+    for _ in range(length):
+        out.append(out[-offset])
+
+
+def test_copies_across_64k_output_tiles(ctx):
+    """Valid snappy that no block-wise encoder writes: copies whose source lies in an earlier 64 KiB tile of
+    the output, copies that run over a tile boundary, far 4-byte offsets.  snappy.Decode reads them all."""
     rng = np.random.default_rng(3)
     a = bytes(rng.integers(0, 256, 65530, dtype=np.uint8))
     b = bytes(rng.integers(0, 256, 10, dtype=np.uint8))
-    lit = lambda x: (bytes([61 << 2]) + (len(x) - 1).to_bytes(2, "little") if len(x) > 60 else bytes([(len(x) - 1) << 2])) + x
-    block = _uvarint(65530 + 10 + 8) + lit(a) + lit(b) + bytes([(7 << 2) | 2, 12, 0])
-    want, err = O.snappy_decode(block)
-    assert err == 0 and want == a + b + (a + b)[-12:-4]
-    with pytest.raises(N.PqdError) as e:
-        R.snappy_decode_blocks(ctx, [block])
-    assert e.value.code == N.E_UNSUPPORTED
+    blocks, wants = [], []
+    # source in the previous tile
+    blocks.append(_uvarint(65530 + 10 + 8) + _lit(a) + _lit(b) + _copy(8, 12))
+    wants.append(a + b + (a + b)[-12:-4])
+    # a copy that starts 6 bytes before the boundary and ends behind it; then copies of its bytes
+    out = bytearray(a)
+    body = _lit(a)
+    for length, offset, kind in [(40, 1000, 2), (8, 8, 1), (30, 3, 2), (64, 65000, 2), (64, 65536 + 50, 4), (11, 2047, 1)]:
+        body += _copy(length, offset, kind)
+        _apply(out, length, offset)
+    blocks.append(_uvarint(len(out)) + body)
+    wants.append(bytes(out))
+    # a run (offset 1) over two tile boundaries, written as copies of 64
+    out = bytearray(b"ab")
+    body = _lit(b"ab")
+    while len(out) < 3 * 65536 + 100:
+        body += _copy(64, 1, 2)
+        _apply(out, 64, 1)
+    body += _copy(64, 140000, 4)
+    _apply(out, 64, 140000)
+    blocks.append(_uvarint(len(out)) + body)
+    wants.append(bytes(out))
+    for blk, want in zip(blocks, wants):
+        assert O.snappy_decode(blk) == (want, 0)
+    got = R.snappy_decode_blocks(ctx, blocks)
+    for i, (g, w) in enumerate(zip(got, wants)):
+        assert g == w, i
+    # one at a time too (a batch of one block)
+    assert R.snappy_decode_blocks(ctx, blocks[1:2]) == wants[1:2]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_element_streams_with_a_wide_window(ctx, seed):
+    """Random literals and copies with offsets up to everything written so far (all three copy tags), about 400 KB of
+    output per block: most copies reach into earlier tiles, and copies of copies form chains across them."""
+    rng = np.random.default_rng(100 + seed)
+    blocks, wants = [], []
+    for target in (200_000, 400_000, 70_000):
+        out = bytearray()
+        body = bytearray()
+        while len(out) < target:
+            if not out or rng.random() < 0.3:
+                x = bytes(rng.integers(0, 256, int(rng.integers(1, 120)), dtype=np.uint8))
+                body += _lit(x)
+                out += x
+            else:
+                length = int(rng.integers(1, 65))
+                r = rng.random()
+                hi = len(out) if r < 0.5 else min(len(out), 70_000) if r < 0.8 else min(len(out), 40)
+                offset = int(rng.integers(1, hi + 1))
+                kind = None if rng.random() < 0.8 else 4
+                body += _copy(length, offset, kind)
+                _apply(out, length, offset)
+        blocks.append(_uvarint(len(out)) + bytes(body))
+        wants.append(bytes(out))
+    for blk, want in zip(blocks, wants):
+        assert O.snappy_decode(blk) == (want, 0)
+    got = R.snappy_decode_blocks(ctx, blocks)
+    for i, (g, w) in enumerate(zip(got, wants)):
+        assert g == w, (seed, i)
