@@ -83,6 +83,9 @@ struct pqd_plan {
     ChainArgs schain = {};
     LvArgs lv = {};
     RegionTotal* d_stotals = nullptr;
+    std::vector<u32> str_chunk_prefix;  // first string region (page) of every BYTE_ARRAY chunk, and the total
+    u32* d_str_chunk_prefix = nullptr;
+    PageDyn* d_str_pd = nullptr;        // per string region: where the page's strings go in the chunk's arrays
     PageDyn* d_page_dyn = nullptr; ChunkDyn* d_chunk_dyn = nullptr; RowTile* d_row_tiles = nullptr;
     int* d_status = nullptr;
     u8 *ff_begin = nullptr, *zero_begin = nullptr;  // per-run reset ranges
@@ -384,6 +387,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     bool ovf = false;
     for (size_t c = 0; c < n_chunks; c++) {
         const ChunkRec& C = pl->chunks[c];
+        if (C.phys_type == PQD_BYTE_ARRAY) pl->str_chunk_prefix.push_back((u32)pl->sregions.size());
         for (u32 k = 0; k < C.n_pages; k++) {
             const u32 pi = C.first_page + k;
             const PageRec& P = pl->pages[pi];
@@ -438,6 +442,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         }
     }
     if (ovf) return fail(ctx, PQD_E_UNSUPPORTED, "batch too large for 32-bit tile indices");
+    pl->str_chunk_prefix.push_back((u32)pl->sregions.size());
     pl->n_lvtiles = (u32)n_lv;
     // workgroups take super-tiles in this order: super-tile t of every block before super-tile t + 1 of any, so
     // the one a workgroup waits for was always taken earlier, and the chains of all blocks advance side by side
@@ -475,6 +480,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const u32 n_ssupers = pl->ssuper_prefix.back();
     const size_t o_ssexit = ap.take((size_t)n_ssupers * CH_E_STRINGS * sizeof(ExitRec));
     const size_t o_stot = ap.take(pl->sregions.size() * sizeof(RegionTotal));
+    const size_t o_scpf = ap.take(pl->str_chunk_prefix.size() * 4), o_spd = ap.take(pl->sregions.size() * sizeof(PageDyn));
     const size_t o_rtiles = ap.take((size_t)pl->n_rtiles * sizeof(RowTile));
     const size_t o_cdyn = ap.take(n_chunks * sizeof(ChunkDyn));
     const bool lv_stamps = getenv("PQD_LV_STAMPS") != nullptr;  // diagnostics: per-workgroup phase stamps of k_levels
@@ -569,6 +575,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->d_row_chunks = (u32*)(A + o_rc); pl->d_rtile_prefix = (u32*)(A + o_rtp);
     pl->d_sexit = (ExitRec*)(A + o_sexit);
     pl->d_stotals = (RegionTotal*)(A + o_stot);
+    pl->d_str_chunk_prefix = (u32*)(A + o_scpf); pl->d_str_pd = (PageDyn*)(A + o_spd);
     pl->d_row_tiles = (RowTile*)(A + o_rtiles);
     pl->d_chunk_dyn = (ChunkDyn*)(A + o_cdyn);
     pl->d_stile_entry = (TileEntry*)(A + o_ste);
@@ -591,6 +598,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if ((rc = upload(ctx, pl->d_pages, pl->pages))) return rc;
     if ((rc = upload(ctx, pl->d_lregions, pl->lregions))) return rc;
     if ((rc = upload(ctx, pl->d_sregions, pl->sregions))) return rc;
+    if ((rc = upload(ctx, pl->d_str_chunk_prefix, pl->str_chunk_prefix))) return rc;
     if ((rc = upload(ctx, (LvTile*)(A + o_lvo), pl->lv_order))) return rc;
     pl->d_vidx_pages = (u32*)(A + o_vip); pl->d_lvl_off = (u64*)(A + o_plo);
     if ((rc = upload(ctx, pl->d_vidx_pages, pl->vidx_pages))) return rc;
@@ -630,9 +638,9 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
 
     // Three streams.  The PLAIN value gather is independent of the levels (the reference reads the concatenated
     // values regions as one stream) and HBM-bound, while the level and string kernels are instruction-bound, so
-    // the gather runs beside them on a stream of its own.  The first pass over the strings (exit tables, hops,
-    // totals) needs nothing from the levels either and goes to another side stream; only the strings' marking
-    // pass waits for the value counts.  Levels, page scan, bools and row offsets stay on the main stream.
+    // the gather runs beside them on a stream of its own.  The strings (exit tables, hops, totals, marking pass)
+    // need nothing from the levels either and go to another side stream; only the final comparison of their
+    // counts with the levels' waits.  Levels, page scan, bools and row offsets stay on the main stream.
     const bool str_early = ctx->overlap && n_lreg && n_sreg;
     const bool copy_side = ctx->overlap && pl->n_copy_blocks && (n_lreg || n_sreg);
     hipStream_t cst = copy_side ? ctx->stream3 : st, sst = str_early ? ctx->stream2 : st;
@@ -642,10 +650,15 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     HIP_TRY(ctx, launch_copy(cst, src, pl->d_segs, pl->d_seg_blk_prefix, (u32)pl->segs.size(), pl->n_copy_blocks, ctx->copy_grid));
     if (ev_c1) HIP_TRY(ctx, hipEventRecord(ev_c1, cst));
     if (copy_side) HIP_TRY(ctx, hipEventRecord(pl->ev_join_copy, cst));
-    if (str_early) {
-        HIP_TRY(ctx, hipStreamWaitEvent(sst, pl->ev_fork, 0));
-        HIP_TRY(ctx, launch_chain(sst, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 0));
-        HIP_TRY(ctx, hipEventRecord(pl->ev_join, sst));
+    // strings, both passes: a page's place in the chunk's offsets and chars follows from the string counts of the
+    // first pass (k_str_page_scan), so nothing here waits for the levels; k_str_check compares with them at the end
+    if (n_sreg) {
+        if (str_early) HIP_TRY(ctx, hipStreamWaitEvent(sst, pl->ev_fork, 0));
+        HIP_TRY(ctx, launch_chain(sst, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_str_pd, pl->d_status, 0));
+        HIP_TRY(ctx, launch_str_page_scan(sst, pl->d_sregions, pl->d_str_chunk_prefix, (u32)pl->str_chunk_prefix.size() - 1,
+                                          pl->d_stotals, pl->d_str_pd));
+        HIP_TRY(ctx, launch_chain(sst, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_str_pd, pl->d_status, 1));
+        if (str_early) HIP_TRY(ctx, hipEventRecord(pl->ev_join, sst));
     }
 
     // levels, then everything that only needs them
@@ -658,8 +671,6 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
                              pl->d_row_tiles, pl->d_chunk_dyn));
     if (n_sreg) {
         if (str_early) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join, 0));
-        else HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 0));
-        HIP_TRY(ctx, launch_chain(st, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_page_dyn, pl->d_status, 1));
         HIP_TRY(ctx, launch_str_check(st, pl->d_pages, pl->d_chunks, pl->d_page_dyn, pl->d_sregions, n_sreg, pl->d_stotals, pl->d_status));
     }
     if (copy_side) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join_copy, 0));

@@ -190,6 +190,10 @@ hipError_t launch_value_index(hipStream_t st, const ChunkRec* chunks, const Page
                               const u32* page_ids, u32 n_pages, const u64* page_lvl_off);
 hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids, const u32* btile_prefix,
                         u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn, const int* status);
+// strings: per-page value and char offsets within the chunk from the first pass's string counts (one wave per
+// string chunk; region_prefix has n_str_chunks + 1 entries); str_pd is indexed by string region
+hipError_t launch_str_page_scan(hipStream_t st, const Region* regions, const u32* region_prefix, u32 n_str_chunks,
+                                const RegionTotal* totals, PageDyn* str_pd);
 hipError_t launch_str_check(hipStream_t st, const PageRec* pages, const ChunkRec* chunks, const PageDyn* page_dyn,
                             const Region* regions, u32 n_regions, const RegionTotal* totals, int* status);
 hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_prefix, const u32* chunk_ids, u32 n_rchunks,

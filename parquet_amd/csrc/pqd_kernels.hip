@@ -925,7 +925,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
 #pragma unroll
     for (u32 t = 0; t < STR_MG; t++) {
         R[t] = regions[ri[t]];
-        pd[t] = page_dyn[R[t].page];
+        pd[t] = page_dyn[ri[t]];  // one entry per string page (region), from k_str_page_scan
     }
 #pragma unroll
     for (u32 t = 0; t < STR_MG; t++) {
@@ -1732,6 +1732,44 @@ __global__ __launch_bounds__(256) void k_bools(const u8* __restrict__ src_base, 
     }
 }
 
+// k_str_page_scan — one wave per BYTE_ARRAY chunk: where each page's strings go in the chunk's offsets and chars
+// arrays, from the string counts the first pass found in the pages themselves (a page's strings are its non-null
+// values, so the level decode would say the same; k_str_check compares the two afterwards).  The marking pass
+// therefore needs nothing from the levels.  region_prefix[k] = first string region (page) of the k-th string chunk.
+__global__ __launch_bounds__(64) void k_str_page_scan(const Region* __restrict__ regions, const u32* __restrict__ region_prefix,
+                                                      u32 n_str_chunks, const RegionTotal* __restrict__ totals,
+                                                      PageDyn* __restrict__ str_pd) {
+    const u32 c = blockIdx.x;
+    if (c >= n_str_chunks) return;
+    const u32 r0 = region_prefix[c], r1 = region_prefix[c + 1], lane = threadIdx.x;
+    u64 run_vals = 0, run_chars = 0;
+    for (u32 base = r0; base < r1; base += 64) {
+        const u32 r = base + lane;
+        u64 nn = 0, chars = 0;
+        if (r < r1) {
+            const Region R = regions[r];
+            const RegionTotal T = totals[r];
+            nn = T.err ? 0 : T.cnt;
+            if (nn > R.n_out) nn = R.n_out;  // never more values than levels: the arrays are sized for that
+            chars = 4 * nn <= R.len ? R.len - 4 * nn : 0;
+        }
+        u64 sv = nn, sc = chars;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u64 tv = __shfl_up(sv, d), tc = __shfl_up(sc, d);
+            if (lane >= (u32)d) { sv += tv; sc += tc; }
+        }
+        if (r < r1) {
+            PageDyn D;
+            D.nn = (u32)nn; D.pad = 0;
+            D.val_off = run_vals + sv - nn;
+            D.char_off = run_chars + sc - chars;
+            str_pd[r] = D;
+        }
+        run_vals += __shfl(sv, 63);
+        run_chars += __shfl(sc, 63);
+    }
+}
+
 // Checks after the string chain: every page must hold exactly as many values as its levels say and
 // end on its last byte.
 __global__ void k_str_check(const Region* __restrict__ regions, u32 n_regions, const RegionTotal* __restrict__ totals,
@@ -2321,6 +2359,14 @@ hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, con
                         u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn, const int* status) {
     if (n_btiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_bools, dim3(n_btiles), dim3(256), 0, st, src, pages, page_ids, btile_prefix, n_bpages, chunks, page_dyn, status);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_str_page_scan(hipStream_t st, const Region* regions, const u32* region_prefix, u32 n_str_chunks,
+                                const RegionTotal* totals, PageDyn* str_pd) {
+    if (n_str_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_str_page_scan, dim3(n_str_chunks), dim3(64), 0, st, regions, region_prefix, n_str_chunks, totals, str_pd);
     LAUNCH_CHECK();
     return hipSuccess;
 }
