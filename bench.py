@@ -244,7 +244,7 @@ DOMINANT = {"flat": "k_copy (PLAIN value gather)", "optint": "k_levels (single-p
             "optional": "k_str_exits / k_str_mark (BYTE_ARRAY chain)", "optstr": "k_str_exits / k_str_mark (BYTE_ARRAY chain)",
             "nested": "k_levels (single-pass level decode) and k_rows (row offsets)",
             "bools": "k_bools (bit -> byte expansion) and k_levels",
-            "mixed": "k_str_exits / k_str_mark (BYTE_ARRAY chain), k_levels and k_copy on two streams"}
+            "mixed": "k_copy, k_str_mark, k_str_exits and k_levels, side by side on three streams"}
 DESCRIBE = {
     "mixed": "this GPU's share of configs[4]: configs[1]+[2]+[3] columns side by side (flat int32/int64/float64, optional int32 + string with "
              "10%% nulls, Person{Being,Username,Friends []Being}), %d rows/page, %d page(s)/chunk, %d row groups per GPU (uncompressed DATA_PAGE v1)",
@@ -407,7 +407,7 @@ def main():
             },
             "collective": {"backend": ("rccl (torch nccl)" if args.dist_backend == "nccl" else "gloo") if use_dist else "none", "world": world},
             # whole step: algorithmic bytes of one plan run / its device time (HIP events on the decoder's stream, average
-            # over the timed steps); a step is a fixed sequence of launches on two streams, so there is no single launch
+            # over the timed steps); a step is a fixed sequence of launches on three streams, so there is no single launch
             "roofline": {
                 "bound": "hbm",
                 "kernel": "whole step; dominant: " + DOMINANT[args.workload],
@@ -423,7 +423,7 @@ def main():
                                    "achieved_counting_them": round((alg + extra) / (step_ms * 1e-3) / 1e9, 1)},
                 "plain_gather": {"kernel": "k_copy", "launch_ms_avg": round(cp_ms, 5), "algorithmic_bytes_per_launch": copy_bytes,
                                  "achieved": round(copy_bytes / (cp_ms * 1e-3) / 1e9, 1) if cp_ms > 0 and copy_bytes else 0.0,
-                                 "note": "runs beside the level and string kernels on a second stream"},
+                                 "note": "runs beside the level and string kernels on a stream of its own, so its launch spans most of the step"},
             },
             "device_ms_per_step_events": round(step_ms, 4),
             "setup_seconds": round(t_build, 1),
