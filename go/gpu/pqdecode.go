@@ -216,6 +216,41 @@ func (r *Result) Strings(chunk int) ([]string, error) {
 	return out, nil
 }
 
+// Scattered returns the values of an optional chunk at their level slots (pqd_plan_scatter): slotBytes = 4 or 8 for
+// the fixed-width types, 1 for bools; nulls read as zero.  For a BYTE_ARRAY chunk pass slotBytes = 4 and get the
+// NLevels+1 slot offsets into OutChars (a null has length 0).  The dense Values plus Defs stay what Scan consumes
+// (performance/parquet.go:104-113); this is for callers that want one entry per row.
+func (r *Result) Scattered(chunk int, slotBytes int, strings bool) ([]byte, error) {
+	ci, err := r.Info(chunk)
+	if err != nil {
+		return nil, err
+	}
+	n := ci.NLevels
+	if strings {
+		n++
+	}
+	size := C.size_t(n * int64(slotBytes))
+	if size == 0 {
+		return nil, nil
+	}
+	dev := C.pqd_device_alloc(r.ctx.h, size)
+	if dev == nil {
+		return nil, fmt.Errorf("pqd_device_alloc of %d bytes failed", int64(size))
+	}
+	defer C.pqd_device_free(r.ctx.h, dev)
+	if rc := C.pqd_plan_scatter(r.plan, C.size_t(chunk), dev, size); rc != 0 {
+		return nil, fmt.Errorf("pqd_plan_scatter: status %d: %s", int(rc), r.ctx.lastError())
+	}
+	if rc := C.pqd_plan_sync(r.plan); rc != 0 {
+		return nil, fmt.Errorf("pqd_plan_sync: status %d: %s", int(rc), r.ctx.lastError())
+	}
+	out := make([]byte, int(size))
+	if rc := C.pqd_copy_to_host(r.ctx.h, unsafe.Pointer(&out[0]), dev, size); rc != 0 {
+		return nil, fmt.Errorf("pqd_copy_to_host: status %d: %s", int(rc), r.ctx.lastError())
+	}
+	return out, nil
+}
+
 func (r *Result) Close() {
 	if r.plan != nil {
 		C.pqd_plan_destroy(r.plan)

@@ -152,6 +152,16 @@ const void* pqd_plan_device_ptr(pqd_plan* plan, size_t chunk, pqd_output which);
  * (>= 0) or a negative status. */
 int64_t pqd_plan_fetch(pqd_plan* plan, size_t chunk, pqd_output which, void* dst, size_t cap);
 
+/* Null-mask scatter of one chunk of the last run: its values at their level slots, for consumers that want one
+ * entry per level (row, for a column that is not repeated) instead of the dense f.vals plus levels that the
+ * reference's Scan consumes (valsFromDefs fields.go:216-228; performance/parquet.go:104-113).
+ * Fixed width and bool: dst[i] = the value of level i, 0 where validity bit i is clear; n_levels entries of
+ * 4 / 8 / 1 bytes.  BYTE_ARRAY: int32[n_levels + 1] offsets into CHARS, dst[i + 1] - dst[i] = length of the
+ * string of level i and 0 for a null.  Columns with definition levels only (PQD_E_ARG otherwise).
+ * `dst_device` is device memory of the caller, 16-byte aligned, at least n_levels * w (strings:
+ * (n_levels + 1) * 4) bytes.  Queued on the decoder's stream behind the last run; pqd_plan_sync waits for it. */
+int pqd_plan_scatter(pqd_plan* plan, size_t chunk, void* dst_device, size_t dst_bytes);
+
 /* Diagnostics: when the plan was created with PQD_LV_STAMPS set in the environment, the level kernel of the
  * last run left 16 wall-clock stamps (100 MHz) per workgroup; copies them to `dst` and returns the bytes
  * (0 when the plan has none). */

@@ -817,6 +817,23 @@ int64_t pqd_plan_fetch(pqd_plan* pl, size_t c, pqd_output which, void* dst, size
     return (int64_t)n;
 }
 
+int pqd_plan_scatter(pqd_plan* pl, size_t c, void* dst_device, size_t dst_bytes) {
+    if (!pl || c >= pl->chunks.size() || !pl->ran) return PQD_E_ARG;
+    pqd_ctx* ctx = pl->ctx;
+    const ChunkRec& C = pl->chunks[c];
+    if (C.max_def <= 0) return fail(ctx, PQD_E_ARG, "scatter: the column has no definition levels (its values are its slots)");
+    const bool strings = C.phys_type == PQD_BYTE_ARRAY;
+    const int w = strings ? 4 : C.phys_type == PQD_BOOLEAN ? 1 : (int)C.width_bytes;
+    if (w != 1 && w != 4 && w != 8) return fail(ctx, PQD_E_UNSUPPORTED, "scatter: value width");
+    const u64 n_slots = C.n_levels + (strings ? 1 : 0);
+    if (!dst_device || ((uintptr_t)dst_device & 15) || dst_bytes < n_slots * (u64)w)
+        return fail(ctx, PQD_E_ARG, "scatter: destination missing, not 16-byte aligned or too small");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_scatter(ctx->stream, w, strings, C.validity, C.value_index, strings ? C.offsets : C.values, (u8*)dst_device,
+                                n_slots, (C.n_levels + 63) / 64));
+    return PQD_OK;
+}
+
 int64_t pqd_plan_debug_stamps(pqd_plan* pl, void* dst, size_t cap) {
     if (!pl || !pl->lv.stamps) return 0;
     const size_t n = (size_t)pl->n_lvtiles * LV_STAMPS * 8;

@@ -1700,6 +1700,42 @@ __global__ __launch_bounds__(1024) void k_value_index(const ChunkRec* __restrict
 }
 
 // =====================================================================================
+// k_scatter — null-mask scatter: the dense values of a column with definition levels at their level slots.
+// Slot i holds values[value index of i] when level i is non-null and 0 otherwise; the value index is
+// value_index[i / 64] + popcount(validity bits of word i / 64 below bit i % 64).  OFFSETS (strings): the int32
+// offsets at their slots, n_levels + 1 of them; a null slot takes the offset of the next value, so its string
+// is empty.  One thread writes 16 bytes: 16 / W slots, all inside one validity word.
+// =====================================================================================
+template <int W, bool OFFSETS>
+__global__ __launch_bounds__(256) void k_scatter(const u64* __restrict__ validity, const u32* __restrict__ value_index,
+                                                 const u8* __restrict__ values, u8* __restrict__ dst, u64 n_slots, u64 n_words) {
+    constexpr u32 PER = 16 / W;
+    const u64 i0 = ((u64)blockIdx.x * 256 + threadIdx.x) * PER;
+    if (i0 >= n_slots) return;
+    const u64 wi = i0 >> 6;
+    const u64 word = wi < n_words ? validity[wi] : 0;  // strings: the slot behind the last level may open a new word
+    const u32 sh = (u32)(i0 & 63);
+    u32 vi = value_index[wi] + (u32)__popcll(word & ((1ull << sh) - 1));
+    const u32 bits = (u32)(word >> sh);
+    u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (u32 j = 0; j < PER; j++) {
+        const bool on = (bits >> j) & 1;
+        if (OFFSETS || on) {
+            if (i0 + j < n_slots) {
+                if (W == 1) o[j >> 2] |= (u32)values[vi] << (8 * (j & 3));
+                else if (W == 4) o[j] = ((const u32*)values)[vi];
+                else { const u64 v = ((const u64*)values)[vi]; o[2 * j] = (u32)v; o[2 * j + 1] = (u32)(v >> 32); }
+            }
+        }
+        vi += on ? 1u : 0u;
+    }
+    u8* const d = dst + i0 * W;
+    if (i0 + PER <= n_slots) *(u32x4*)d = u32x4{o[0], o[1], o[2], o[3]};
+    else for (u32 k = 0; k < (u32)(n_slots - i0) * W; k++) d[k] = (u8)(o[k >> 2] >> (8 * (k & 3)));
+}
+
+// =====================================================================================
 // k_bools — PLAIN booleans: bit i%8 of byte i/8, LSB first, restarting at a byte boundary on every
 // page (parquet.go:465-471).  One thread produces 16 output bytes.
 // =====================================================================================
@@ -2359,6 +2395,23 @@ hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, con
                         u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn, const int* status) {
     if (n_btiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_bools, dim3(n_btiles), dim3(256), 0, st, src, pages, page_ids, btile_prefix, n_bpages, chunks, page_dyn, status);
+    LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_scatter(hipStream_t st, int width, bool offsets, const u8* validity, const u8* value_index, const u8* values,
+                          u8* dst, u64 n_slots, u64 n_words) {
+    if (n_slots == 0) return hipSuccess;
+    const u32 per = 16 / (u32)width;
+    const u64 n_thr = (n_slots + per - 1) / per, grid = (n_thr + 255) / 256;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    const u64* vb = (const u64*)validity;
+    const u32* vx = (const u32*)value_index;
+    if (offsets) hipLaunchKernelGGL((k_scatter<4, true>), dim3((u32)grid), dim3(256), 0, st, vb, vx, values, dst, n_slots, n_words);
+    else if (width == 1) hipLaunchKernelGGL((k_scatter<1, false>), dim3((u32)grid), dim3(256), 0, st, vb, vx, values, dst, n_slots, n_words);
+    else if (width == 4) hipLaunchKernelGGL((k_scatter<4, false>), dim3((u32)grid), dim3(256), 0, st, vb, vx, values, dst, n_slots, n_words);
+    else if (width == 8) hipLaunchKernelGGL((k_scatter<8, false>), dim3((u32)grid), dim3(256), 0, st, vb, vx, values, dst, n_slots, n_words);
+    else return hipErrorInvalidValue;
     LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -182,6 +182,27 @@ class Plan:
             _check(int(n), self.ctx.handle)
         return buf[:n].view(dtype)
 
+    def scatter(self, chunk):
+        """Null-mask scatter of one chunk (pqd_plan_scatter): one entry per level, 0 for nulls; for strings the
+        n_levels + 1 slot offsets into CHARS.  Returns a numpy array copied from the device."""
+        cd = self._chunks[chunk]
+        ci = self.info(chunk)
+        strings = cd.phys_type == N.BYTE_ARRAY
+        dt = np.dtype(np.int32) if strings else np.dtype(np.uint8) if cd.phys_type == N.BOOLEAN else np.dtype(_DTYPES[cd.phys_type])
+        n = ci.n_levels + (1 if strings else 0)
+        nbytes = max(n * dt.itemsize, 16)
+        dev = N.decode.pqd_device_alloc(self.ctx.handle, nbytes)
+        if not dev:
+            raise MemoryError("pqd_device_alloc")
+        try:
+            _check(N.decode.pqd_plan_scatter(self._h, chunk, dev, nbytes), self.ctx.handle)
+            self.sync()
+            out = np.zeros(nbytes, np.uint8)
+            _check(N.decode.pqd_copy_to_host(self.ctx.handle, out.ctypes.data, dev, nbytes), self.ctx.handle)
+        finally:
+            N.decode.pqd_device_free(self.ctx.handle, dev)
+        return out[: n * dt.itemsize].view(dt)
+
     def column(self, chunk):
         """All decoded arrays of one chunk as a dict of numpy arrays (the Field's vals / Defs / Reps)."""
         cd = self._chunks[chunk]
