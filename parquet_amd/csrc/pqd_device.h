@@ -49,8 +49,8 @@ constexpr u32 CH_SUPER = 16;      // groups per super-group (strings only)
 constexpr u32 chain_group_tiles(int kind) { return kind == KIND_LEVELS ? CH_G_LEVELS : kind == KIND_STRINGS ? CH_G_STRINGS : CH_G_SNAPPY; }
 
 constexpr u32 OT = 4096;          // level values per expand tile
-constexpr u32 SN_SPIN_MAX = 1u << 22;  // snappy: polls of a pending copy before it is given up (safety net)
-constexpr u32 SN_T = 65536;       // snappy: output bytes per decode tile (the block size of the usual encoders)
+constexpr u32 SN_SPIN_MAX = 1u << 22;  // snappy: polls of an earlier tile's flag before a workgroup gives up (safety net, never reached)
+constexpr u32 SN_T = 32768;       // snappy: output bytes per decode tile (half the block size of the usual encoders: 15-bit tile positions)
 constexpr u32 EX_CAP = 1024;      // runs staged in LDS per expand batch
 constexpr u32 BT = 4096;          // bools per tile
 constexpr u32 RT = 4096;          // levels per row-offset tile

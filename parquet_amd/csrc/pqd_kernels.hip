@@ -17,6 +17,7 @@
 //   k_rows_*          per-row level consumption of the generated write functions
 //                     (cmd/parquetgen/dremel/write_repeated.go:62-80, write_optional.go:22-31)
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "pqd_device.h"
@@ -1823,296 +1824,262 @@ __global__ void k_str_check(const Region* __restrict__ regions, u32 n_regions, c
 }
 
 // =====================================================================================
-// k_snappy_tiles — decodes SN_T = 64 KiB of one snappy block's output per workgroup, in LDS, from the
-// element records the chain kernels left (out_off, literal position or copy offset).
-//   1. literals: every wave takes 64 elements at a time and copies their literals one after the other
-//      with all lanes (a 64 KiB literal of incompressible data is just a long copy loop);
-//   2. copies: a bitmap says which output bytes are final; the waves take chunks of 64 elements in
-//      order, one copy per lane, and a copy runs as soon as every byte of its source range is final,
-//      then marks its own bytes.  Chains of copies of copies resolve at LDS latency, without workgroup
-//      barriers.  A copy that overlaps its own output (offset < length) repeats its pattern as the
-//      format says;
-//   3. the tile leaves as aligned 16-byte stores.
-// The usual encoders (golang/snappy, C++ snappy) compress 64 KiB blocks independently, so their copies stay
-// inside a tile.  snappy.Decode takes any offset up to the bytes written so far, so a copy may also reach into
-// (or continue from) an earlier tile: those source bytes are read from the earlier tile's output in memory once
-// that tile has raised its flag in `tile_done`.  Workgroups take their tile from a ticket counter, so the tiles a
-// workgroup waits for belong to workgroups that already run.
-// d < offset (a copy reaching before the start of the output) is ErrCorrupt.
+// k_snappy_ptr — decodes SN_T = 32 KiB of one snappy block's output per workgroup, in LDS, from the element
+// records the chain kernels left (out_off, literal position or copy offset).
+// Every output byte of the tile gets a 16-bit entry: either its value (a literal byte) or the tile position of
+// the byte it copies (d[k] = d[k - offset], per byte, which also covers copies that overlap their own output).
+// Rounds of x[i] = x[x[i]] then shorten every chain of copies of copies at once (after r rounds an entry has
+// followed 2^r links), so the time depends on log2 of the dependency depth, not on the depth: a kernel that ran
+// each copy when its source bytes were final took 0.5 us per link and 585 us per 64 KiB of run-like data.
+// Entries are updated in place without barriers inside a round: whatever an entry holds at any time stands for
+// the same byte value.  Last, 16 entries per thread are turned into 16 bytes and stored.
+// snappy.Decode takes any offset up to the bytes written so far, so a copy may reach into (or continue from) an
+// earlier tile; with the 64 KiB blocks of the usual encoders the odd tiles do.  Such a byte points at itself until
+// the tiles that hold its source have raised their flags in `tile_done`; it is then fetched from the block's
+// output in memory.  Workgroups take their tile from a ticket counter, so the tiles a workgroup waits for belong
+// to workgroups that already run.  d < offset (a copy reaching before the start of the output) is ErrCorrupt.
 // =====================================================================================
-constexpr u32 SN_THREADS = 256;  // 4 waves per 64 KiB tile (8 are 11 % faster on text and 12 % slower on long runs,
-                                  // where the extra waves only wait; 6 fit one tile per CU and lose everywhere)
-__global__ __launch_bounds__(SN_THREADS) void k_snappy_tiles(const u8* __restrict__ src_base, const Region* __restrict__ regions,
-                                                      const u32* __restrict__ otile_region, const RunRec* __restrict__ run_tbl,
-                                                      const u32* __restrict__ otile_first_run,
-                                                      const RegionTotal* __restrict__ totals, int* __restrict__ status,
-                                                      u32* __restrict__ tile_done, u32* __restrict__ ticket, u32 n_otiles) {
-    __shared__ __attribute__((aligned(16))) u8 s_o[SN_T];
-    __shared__ u32 s_fin[SN_T / 32];  // bit i: output byte i of the tile is final
-    __shared__ u32 s_next, s_ticket;
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+constexpr u32 SP_THREADS = 512;     // 8 waves per tile, two tiles per CU: the rounds are chains of dependent LDS reads and want waves to switch to
+constexpr u32 SP_LIT = 0x8000u;       // entry = SP_LIT | byte value; otherwise a tile position
+constexpr u32 SP_LONG_MAX = 512;      // literals of more than 64 bytes per tile
+static_assert(SN_T <= 32768 && SN_T % (SP_THREADS * 16) == 0, "15-bit tile positions; whole rounds of 16 entries per thread");
+static_assert(SN_T / 65 < SP_LONG_MAX, "every long literal of a tile has a slot");
+static __device__ __forceinline__ u32 sp_byte(const u32x4& v, int k) {
+    const u32 w = (k >> 2) == 0 ? v.x : (k >> 2) == 1 ? v.y : (k >> 2) == 2 ? v.z : v.w;
+    return (w >> (8 * (k & 3))) & 0xFF;
+}
+// the 4 bytes of w as 4 value entries
+static __device__ __forceinline__ u64 sp_lit4(u32 w) {
+    const u32 lo = (w & 0xFF) | ((w & 0xFF00) << 8) | (SP_LIT | (SP_LIT << 16));
+    const u32 hi = ((w >> 16) & 0xFF) | ((w >> 8) & 0xFF0000) | (SP_LIT | (SP_LIT << 16));
+    return lo | ((u64)hi << 32);
+}
+// n (<= 64) value entries from the bytes of v at entry d (LDS takes stores at any alignment): whole groups of 4
+// as one 8-byte store, the rest one by one
+static __device__ __forceinline__ void sp_put_bytes(unsigned short* d, const u32x4 (&v)[4], u32 n) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const u32 wds[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 k = 16 * c + 4 * q;
+            if (k + 4 <= n) *(u64_u*)(d + k) = sp_lit4(wds[q]);
+            else if (k < n) {
+#pragma unroll
+                for (int b = 0; b < 3; b++)
+                    if (k + b < n) d[k + b] = (unsigned short)(SP_LIT | ((wds[q] >> (8 * b)) & 0xFF));
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(SP_THREADS) void k_snappy_ptr(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                                                           const u32* __restrict__ otile_region, const RunRec* __restrict__ run_tbl,
+                                                           const u32* __restrict__ otile_first_run,
+                                                           const RegionTotal* __restrict__ totals, int* __restrict__ status,
+                                                           u32* __restrict__ tile_done, u32* __restrict__ ticket, u32 n_otiles) {
+    __shared__ __attribute__((aligned(16))) unsigned short s_x[SN_T];
+    __shared__ u32 s_long[3 * SP_LONG_MAX];
+    __shared__ u32 s_ticket, s_nlong, s_far_lo;
+    const u32 tid = threadIdx.x;
+    if (tid == 0) { s_ticket = atomicAdd(ticket, 1u); s_nlong = 0; s_far_lo = ERR_POS; }
+    for (u32 i = tid; i < SN_T / 8; i += SP_THREADS) ((u32x4*)s_x)[i] = u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
     __syncthreads();
     const u32 ot = s_ticket;
     if (ot >= n_otiles) return;
     const u32 ri = otile_region[ot];
-    u32 first = otile_first_run[ot];
+    const u32 first = otile_first_run[ot];
     const u32 nf = otile_first_run[ot + 1];
     const bool next_same = otile_region[ot + 1] == ri;
     const Region R = regions[ri];
     const RegionTotal T = totals[ri];
-    if (first == ERR_POS || T.err || T.vals != R.n_out) return;  // corrupt block: status already set
+    if (first == ERR_POS || T.err || T.vals != R.n_out) return;  // corrupt block: status already set, no tile of it waits
     const u32 n_out = (u32)R.n_out;
     const u32 B = (ot - R.otile_base) * SN_T;
     const u32 t_hi = B + SN_T < n_out ? B + SN_T : n_out;
+    const u32 n_tile = t_hi - B;
     const u8* rsrc = src_base + R.src_off;
     const RunRec* runs = run_tbl + R.run_base;
     u32 last = T.cnt;
     if (next_same && nf != ERR_POS && nf + 1 < last) last = nf + 1;
 
-    for (u32 i = tid; i < SN_T / 32; i += SN_THREADS) s_fin[i] = 0;
-    if (tid == 0) s_next = first;
-    __syncthreads();
-    // sets the bits of tile bytes [a, b), all lanes of a wave together
-    auto mark_wave = [&](u32 a, u32 b) {
-        if (b <= a) return;
-        const u32 w0 = a >> 5, w1 = (b - 1) >> 5;
-        for (u32 w = w0 + lane; w <= w1; w += 64) {
-            u32 m = 0xFFFFFFFFu;
-            if (w == w0) m &= 0xFFFFFFFFu << (a & 31);
-            if (w == w1) m &= 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
-            atomicOr(&s_fin[w], m);
+    // ---- 1. one element per thread: literal bytes and copy links.  The records of the next round are requested
+    // before this round's are worked on (a record, then its literal bytes: two dependent trips to memory otherwise).
+    auto fetch = [&](u32 e, RunRec& rr, u32& oe) {
+        if (e < last) {
+            rr = runs[e];
+            oe = e + 1 < T.cnt ? runs[e + 1].out_off : n_out;
         }
     };
-    // ---- 1. literals.  Short ones (the common case) are done lane-parallel, one 16-byte load each, so
-    // that 64 global loads are in flight per wave; long ones are copied by the whole wave in turn.
-    for (u32 base = first + wv * 64; base < last; base += SN_THREADS) {
-        const u32 e = base + lane;
-        u32 lo = 0, hi = 0, sp = 0;
-        bool lit = false;
-        if (e < last) {
-            const RunRec rr = runs[e];
-            const u32 o = rr.out_off, oe = e + 1 < T.cnt ? runs[e + 1].out_off : n_out;
-            lit = !(rr.info & 1);
-            lo = o > B ? o : B;             // a literal may straddle tiles
-            hi = oe < t_hi ? oe : t_hi;
-            sp = (rr.info >> 1) + (lo - o);
-            if (hi <= lo) lit = false;
+    RunRec rr_c = RunRec{0, 0}, rr_n = RunRec{0, 0};
+    u32 oe_c = 0, oe_n = 0;
+    fetch(first + tid, rr_c, oe_c);
+    for (u32 base = first; base < last; base += SP_THREADS) {
+        const u32 e = base + tid;
+        fetch(e + SP_THREADS, rr_n, oe_n);
+        const RunRec rr = rr_c;
+        const u32 o = rr.out_off, oe = oe_c;
+        rr_c = rr_n;
+        oe_c = oe_n;
+        if (e >= last) continue;
+        const u32 lo = o > B ? o : B, hi = oe < t_hi ? oe : t_hi;  // an element may straddle tiles
+        if (hi <= lo) continue;
+        const u32 n = hi - lo, d0 = lo - B;
+        if (!(rr.info & 1)) {
+            const u32 sp = (rr.info >> 1) + (lo - o);
+            if (n <= 64) {
+                u32x4 v[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c] = 16u * c < n ? load_u128_guarded(rsrc, sp + 16 * c, R.len) : u32x4{0, 0, 0, 0};
+                sp_put_bytes(s_x + d0, v, n);
+            } else {
+                const u32 j = atomicAdd(&s_nlong, 1u);
+                if (j < SP_LONG_MAX) { s_long[3 * j] = d0; s_long[3 * j + 1] = n; s_long[3 * j + 2] = sp; }
+            }
+        } else {
+            const u32 off = rr.info >> 1;
+            if (off > o || off == 0) set_status(status, ST_CORRUPT, ri);  // d < offset: the bytes stay zero
+            else {
+                // entry k copies tile position d0 + k - off; a source before the tile: the entry points at itself for
+                // now.  Both are k plus a constant, four entries per store
+                const bool has_far = lo - off < B;
+                const u32 kf = has_far ? (B + off - lo < n ? B + off - lo : n) : 0;  // entries [0, kf) have their source before the tile
+                for (u32 k = 0; k < n; k += 4) {
+                    if (k + 4 <= n && (k >= kf || k + 4 <= kf)) {
+                        const u32 c0 = (k >= kf ? d0 - off : d0) + k;
+                        const u32 w0 = c0 * 0x00010001u + 0x00010000u, w1 = w0 + 0x00020002u;
+                        *(u64_u*)(s_x + d0 + k) = w0 | ((u64)w1 << 32);
+                    } else {
+                        for (u32 b = k; b < k + 4 && b < n; b++) s_x[d0 + b] = (unsigned short)(b >= kf ? d0 + b - off : d0 + b);
+                    }
+                }
+                if (has_far) atomicMin(&s_far_lo, lo - off);
+            }
         }
-        const bool is_short = lit && hi - lo <= 64;
-        if (is_short) {
-            const u32 n = hi - lo;
+    }
+    __syncthreads();
+    // long literals (incompressible stretches), by all threads
+    {
+        const u32 nl = s_nlong < SP_LONG_MAX ? s_nlong : SP_LONG_MAX;
+        for (u32 j = 0; j < nl; j++) {
+            const u32 d0 = s_long[3 * j], n = s_long[3 * j + 1], sp = s_long[3 * j + 2];
+            for (u32 k = tid * 16; k < n; k += SP_THREADS * 16) {
+                const u32x4 v = load_u128_guarded(rsrc, sp + k, R.len);
+                if (((d0 + k) & 1) == 0 && k + 16 <= n) {
+                    u32* const d = (u32*)(s_x + d0 + k);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) d[q] = (SP_LIT | sp_byte(v, 2 * q)) | ((SP_LIT | sp_byte(v, 2 * q + 1)) << 16);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; q++)
+                        if (k + q < n) s_x[d0 + k + q] = (unsigned short)(SP_LIT | sp_byte(v, q));
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. rounds of x[i] = x[x[i]], 8 entries per thread and step, until every entry is a value or points at a
+    // byte that waits for an earlier tile
+    const u32 n_grp = (n_tile + 7) / 8;
+    u32 live = 0xFFFFFFFFu;  // bit t: my t-th group may still change (a group that has settled stays settled)
+    static_assert(SN_T / 8 / SP_THREADS <= 32, "one bit per group of a thread");
+    for (u32 round = 0; round < 20; round++) {  // 15 rounds settle any tile; the bound is a safety net
+        bool unsettled = false;
+        u32 t = 0;
+        for (u32 g = tid; g < n_grp; g += SP_THREADS, t++) {
+            if (!((live >> t) & 1)) continue;
+            const u32x4 own = ((const u32x4*)s_x)[g];
+            const u32 wds[4] = {own.x, own.y, own.z, own.w};
+            u32 xs[8], ys[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) xs[k] = (wds[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
+#pragma unroll
+            for (int k = 0; k < 8; k++) ys[k] = (xs[k] & SP_LIT) ? xs[k] : s_x[xs[k]];  // the reads of a group are in flight together
+            bool g_live = false;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const u32 x = xs[k], y = ys[k], i = g * 8 + k;
+                if ((x & SP_LIT) || x == i) continue;
+                if (y & SP_LIT) s_x[i] = (unsigned short)y;
+                else if (y != x) { s_x[i] = (unsigned short)y; g_live = true; }
+            }
+            if (!g_live) live &= ~(1u << t);
+            unsettled = unsettled || g_live;
+        }
+        if (!__syncthreads_or(unsettled)) break;
+    }
+
+    // ---- 3. bytes copied from earlier tiles of the block
+    const u32 far_lo = s_far_lo;
+    if (far_lo != ERR_POS) {
+        const u32 q0 = far_lo / SN_T, q1 = B / SN_T;  // tiles q0 .. q1 - 1 of the block hold them
+        bool ok = true;
+        for (u32 q = q0 + tid; q < q1 && ok; q += SP_THREADS) {
+            u32 spins = 0;
+            while (!__hip_atomic_load(tile_done + R.otile_base + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (++spins > SN_SPIN_MAX) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        if (!ok) set_status(status, ST_INTERNAL, ri);
+        __syncthreads();
+        // The other tiles' bytes were stored with device-scope stores before their flags went up (below); device-scope
+        // loads read them without a cache invalidate.
+        fetch(first + tid, rr_c, oe_c);
+        for (u32 base = first; base < last; base += SP_THREADS) {
+            const u32 e = base + tid;
+            fetch(e + SP_THREADS, rr_n, oe_n);
+            const RunRec rr = rr_c;
+            const u32 o = rr.out_off, oe = oe_c, off = rr.info >> 1;
+            rr_c = rr_n;
+            oe_c = oe_n;
+            if (e >= last || !(rr.info & 1)) continue;
+            const u32 lo = o > B ? o : B, hi = oe < t_hi ? oe : t_hi;
+            if (hi <= lo || off > o || off == 0 || lo - off >= B) continue;
+            const u32 stop = hi < B + off ? hi : B + off, n = stop - lo, d0 = lo - B, sp = lo - off;  // n <= 64
+            // aligned words that cover [sp, sp + n): at most 17; all of them lie before this tile's first byte or in it,
+            // inside the block's output (R.out is 16-byte aligned and padded to 16 bytes by its owner)
+            const u32* const wp = (const u32*)(R.out + (sp & ~3u));
+            const u32 mis = sp & 3, nw = (mis + n + 3) >> 2;
+            u32 wd[17];
+#pragma unroll
+            for (int q = 0; q < 17; q++) wd[q] = (u32)q < nw ? __hip_atomic_load(wp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             u32x4 v[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) v[c] = 16u * c < n ? load_u128_guarded(rsrc, sp + 16 * c, R.len) : u32x4{0, 0, 0, 0};
-            // LDS takes stores at any alignment: whole 8-byte pieces, and for the rest two overlapping stores
-            // of the largest power of two that fits (first bytes, last bytes) instead of a byte loop
-            u8* d = s_o + (lo - B);
-            const u64 v_lo = v[0].x | ((u64)v[0].y << 32), v_hi = v[0].z | ((u64)v[0].w << 32);
-            if (n >= 16) {
+            for (int c = 0; c < 4; c++)
+                v[c] = u32x4{__builtin_amdgcn_alignbit(wd[4 * c + 1], wd[4 * c], 8 * mis), __builtin_amdgcn_alignbit(wd[4 * c + 2], wd[4 * c + 1], 8 * mis),
+                             __builtin_amdgcn_alignbit(wd[4 * c + 3], wd[4 * c + 2], 8 * mis), __builtin_amdgcn_alignbit(wd[4 * c + 4], wd[4 * c + 3], 8 * mis)};
+            sp_put_bytes(s_x + d0, v, n);
+        }
+        __syncthreads();
+    }
+
+    // ---- 4. 16 entries -> 16 bytes (R.out is 16-byte aligned, B a multiple of the tile size)
+    u8* const dst = R.out + B;
+    for (u32 i = tid * 16; i < n_tile; i += SP_THREADS * 16) {
+        const u32x4 a = *(const u32x4*)(s_x + i), b = *(const u32x4*)(s_x + i + 8);
+        const u32 wds[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        u32 o4[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int c = 0; c < 4; c++)
-                    if (16u * (c + 1) <= n) {
-                        *(u64_u*)(d + 16 * c) = v[c].x | ((u64)v[c].y << 32);
-                        *(u64_u*)(d + 16 * c + 8) = v[c].z | ((u64)v[c].w << 32);
-                    }
-                if (n & 15) {  // the last 16 bytes once more, from the source
-                    const u32x4 t = load_u128_guarded(rsrc, sp + n - 16, R.len);
-                    *(u64_u*)(d + n - 16) = t.x | ((u64)t.y << 32);
-                    *(u64_u*)(d + n - 8) = t.z | ((u64)t.w << 32);
-                }
-            } else if (n >= 8) {
-                const u32 sh = 8 * (n - 8);  // bytes n-8 .. n-1
-                *(u64_u*)d = v_lo;
-                *(u64_u*)(d + n - 8) = sh ? (v_lo >> sh) | (v_hi << (64 - sh)) : v_lo;
-            } else if (n >= 4) {
-                *(u32_u*)d = (u32)v_lo;
-                *(u32_u*)(d + n - 4) = (u32)(v_lo >> (8 * (n - 4)));
-            } else {
-                for (u32 k = 0; k < n; k++) d[k] = (u8)(v_lo >> (8 * k));
-            }
-            const u32 a = lo - B, b = hi - B;  // at most 3 bitmap words
-            for (u32 w = a >> 5; w <= (b - 1) >> 5; w++) {
-                u32 m = 0xFFFFFFFFu;
-                if (w == a >> 5) m &= 0xFFFFFFFFu << (a & 31);
-                if (w == (b - 1) >> 5) m &= 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
-                atomicOr(&s_fin[w], m);
-            }
+        for (int k = 0; k < 16; k++) {
+            u32 x = (wds[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
+            if (!(x & SP_LIT)) x = s_x[x];
+            o4[k >> 2] |= (x & 0xFF) << (8 * (k & 3));
         }
-        u64 m = __ballot(lit && !is_short);
-        while (m) {
-            const int l = __ffsll((unsigned long long)m) - 1;
-            m &= m - 1;
-            const u32 lo_ = __shfl(lo, l), hi_ = __shfl(hi, l), sp_ = __shfl(sp, l);
-            u8* d = s_o + (lo_ - B);
-            const u32 n = hi_ - lo_;
-            const bool aligned = ((lo_ - B) & 3) == 0;
-            for (u32 k = lane * 16; k < n; k += 64 * 16) {  // 1 KiB per wave step
-                const u32x4 v = load_u128_guarded(rsrc, sp_ + k, R.len);
-                if (aligned && k + 16 <= n) {
-                    u32* dw = (u32*)(d + k);
-                    dw[0] = v.x; dw[1] = v.y; dw[2] = v.z; dw[3] = v.w;
-                } else {
-                    const u64 v_lo = v.x | ((u64)v.y << 32), v_hi = v.z | ((u64)v.w << 32);
-                    for (u32 j = 0; j < 16 && k + j < n; j++) d[k + j] = (u8)(j < 8 ? v_lo >> (8 * j) : v_hi >> (8 * (j - 8)));
-                }
-            }
-            mark_wave(lo_ - B, hi_ - B);
+        // Device-scope stores: a later tile of the block, on whichever XCD it runs, may read these bytes once the
+        // flag below is up.  (A device-scope release fence instead would write back the whole L2 once per tile:
+        // measured 1.4 ms per 256 MB of output.)
+        if (i + 16 <= n_tile) {
+            __hip_atomic_store((u64*)(dst + i), o4[0] | ((u64)o4[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((u64*)(dst + i + 8), o4[2] | ((u64)o4[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            for (u32 k = i; k < n_tile; k++)
+                __hip_atomic_store(dst + k, (u8)(o4[(k - i) >> 2] >> (8 * ((k - i) & 3))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    __syncthreads();
-
-    // ---- 2. copies.  Every wave takes the next 64 elements (in order) and loops on its own until all its
-    // copies ran; a copy whose source bytes come from another wave's elements simply stays pending until
-    // their bits appear.  No workgroup barrier: the earliest unfinished chunk can always progress, because
-    // everything before it is final or in the hands of a wave that is running.
-    volatile u32* fin = s_fin;
-    auto mark_range = [&](u32 a, u32 b) {  // a thread's own bytes: at most 64, so at most 3 words
-        for (u32 w = a >> 5; w <= (b - 1) >> 5; w++) {
-            u32 m = 0xFFFFFFFFu;
-            if (w == a >> 5) m &= 0xFFFFFFFFu << (a & 31);
-            if (w == (b - 1) >> 5) m &= 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
-            atomicOr(&s_fin[w], m);
-        }
-    };
-    for (;;) {
-        u32 w0 = 0;
-        if (lane == 0) w0 = atomicAdd(&s_next, 64u);
-        w0 = __shfl(w0, 0);
-        if (w0 >= last) break;
-        const u32 e = w0 + lane;
-        const u32 INF = 0xFFFFFFFFu;
-        bool pending = false, far = false;
-        u32 o = INF, oe = INF, off = 0;  // every lane holds its element's output range, literals too
-        u32 co = 0, len = 0;             // a copy's bytes inside this tile: [co, co + len) of the block's output
-        if (e < last) {
-            const RunRec rr = runs[e];
-            o = rr.out_off;
-            oe = e + 1 < T.cnt ? runs[e + 1].out_off : n_out;
-            if (rr.info & 1) {
-                off = rr.info >> 1;
-                co = o > B ? o : B;
-                const u32 ce = oe < t_hi ? oe : t_hi;
-                len = ce > co ? ce - co : 0;
-                pending = len != 0;
-                if (off > o || off == 0) {                                              // d < offset, offset 0
-                    // its bytes count as final all the same, so that nothing waits for them forever
-                    set_status(status, ST_CORRUPT, ri);
-                    if (len) mark_range(co - B, co - B + len);
-                    pending = false;
-                } else far = pending && co - off < B;  // the first source bytes lie in an earlier tile
-            }
-        }
-        // Copies whose source begins in an earlier tile, one after the other with the whole wave: wait for the
-        // tiles that hold the bytes, fetch them from the block's output in memory, and leave what remains (a
-        // source inside this tile) to the usual way below.
-        for (u64 fm = __ballot(far); fm; fm &= fm - 1) {
-            const int l = __ffsll((unsigned long long)fm) - 1;
-            const u32 f_co = __shfl(co, l), f_len = __shfl(len, l), f_off = __shfl(off, l);
-            const u32 f_n = f_len < B + f_off - f_co ? f_len : B + f_off - f_co;  // bytes whose source lies before B
-            const u32 q0 = (f_co - f_off) / SN_T, q1 = (f_co - f_off + f_n - 1) / SN_T;
-            bool ok = true;
-            for (u32 q = q0 + lane; q <= q1; q += 64) {
-                u32 spins = 0;
-                while (!__hip_atomic_load(tile_done + R.otile_base + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    if (++spins > SN_SPIN_MAX) { ok = false; break; }
-                    __builtin_amdgcn_s_sleep(4);
-                }
-            }
-            if (!__all(ok)) { if (lane == 0) set_status(status, ST_INTERNAL, ri); }
-            __threadfence();  // the other tile's bytes were written before its flag
-            const u8* const g = R.out + (f_co - f_off);
-            for (u32 k = lane; k < f_n; k += 64) s_o[f_co - B + k] = g[k];
-            __threadfence_block();  // bytes before bits
-            mark_wave(f_co - B, f_co - B + f_n);
-            if ((int)lane == l) {
-                co += f_n;
-                len -= f_n;
-                pending = len != 0;
-            }
-        }
-        // source bytes [sa, sb) and own bytes [da, db), tile relative
-        const u32 da = co - B, db = da + len, sa = da - off, sb = sa + (len < off ? len : off);
-        // The part of the source that lies inside this chunk's own output depends on copies of this wave only:
-        // the outputs of the chunk's elements are consecutive, so the lanes whose output overlaps my source are a
-        // contiguous range (two binary searches over the lanes), and waiting for them is a ballot, not a trip
-        // through the bitmap.  The part in front of the chunk waits for the bitmap as before.
-        const u32 sA = co - off, sB = sA + (len < off ? len : off);
-        u32 c_lo = 0, c_hi = 0;  // lanes with oe <= sA / lanes with o < sB
-        {
-            const u32 v = __shfl(oe, 63), v2 = __shfl(o, 63);
-            if (v <= sA) c_lo = 64;
-            if (v2 < sB) c_hi = 64;
-        }
-        for (u32 st = 32; st > 0; st >>= 1) {
-            const u32 i1 = c_lo + st - 1 < 64 ? c_lo + st - 1 : 63, i2 = c_hi + st - 1 < 64 ? c_hi + st - 1 : 63;
-            const u32 v = __shfl(oe, i1), v2 = __shfl(o, i2);
-            if (c_lo + st - 1 < 64 && v <= sA) c_lo += st;
-            if (c_hi + st - 1 < 64 && v2 < sB) c_hi += st;
-        }
-        u64 wait = 0;
-        if (pending && c_hi > c_lo) wait = (c_hi >= 64 ? ~0ull : (1ull << c_hi) - 1) & ~((1ull << c_lo) - 1);
-        wait &= ~(1ull << lane);  // what is left of a copy that began with bytes from an earlier tile may copy those
-        const u32 chunk_o = __shfl(o, 0);
-        const u32 chunk_lo = chunk_o > B ? chunk_o - B : 0;  // tile offset where this chunk's output starts
-        const u32 xb = sb < chunk_lo ? sb : chunk_lo;       // [sa, xb): the source in front of the chunk
-        bool cross = pending && sa < xb;
-        u32 spins = 0;
-        for (;;) {
-            if (cross) {
-                bool fin_ok = true;
-                for (u32 w = sa >> 5; w <= (xb - 1) >> 5; w++) {
-                    u32 m = 0xFFFFFFFFu;
-                    if (w == sa >> 5) m &= 0xFFFFFFFFu << (sa & 31);
-                    if (w == (xb - 1) >> 5) m &= 0xFFFFFFFFu >> (31 - ((xb - 1) & 31));
-                    fin_ok = fin_ok && (fin[w] & m) == m;
-                }
-                cross = !fin_ok;
-            }
-            const u64 pm = __ballot(pending);
-            if (!pm) break;
-            const bool ready = pending && !cross && !(pm & wait);
-            if (ready) {
-                __threadfence_block();  // the bits were set after the bytes they stand for
-                // d[k] = d[k - off], byte by byte in the format's terms.  A byte loop in LDS costs a full LDS
-                // round trip per byte, so bytes move 8 at a time (LDS reads and writes at any alignment).  That
-                // needs a distance of at least 8: an overlapping copy with a shorter offset repeats a pattern of
-                // `off` bytes, and any multiple of `off` is an equally good distance once that many bytes exist.
-                u8* d = s_o + da;
-                u32 o2 = off, k = 0;
-                if (off < 8) {
-                    o2 = off * ((7 + off) / off);
-                    const u32 hd = len < o2 - off ? len : o2 - off;
-                    for (; k < hd; k++) d[k] = d[(int)k - (int)off];
-                }
-                const u32 head = k;
-                for (; k + 8 <= len; k += 8) *(u64_u*)(d + k) = *(const u64_u*)(d + (int)k - (int)o2);
-                if (k < len) {  // the last piece overlaps the one before it instead of a byte loop
-                    if (len - head >= 8) *(u64_u*)(d + len - 8) = *(const u64_u*)(d + (int)(len - 8) - (int)o2);
-                    else for (; k < len; k++) d[k] = d[(int)k - (int)o2];
-                }
-                __threadfence_block();  // bytes before bits
-                mark_range(da, db);
-                pending = false;
-            } else if (pending && ++spins > SN_SPIN_MAX) {
-                // cannot happen while every element marks its bytes; never spin forever on a GPU
-                set_status(status, ST_CORRUPT, ri);
-                mark_range(da, db);
-                pending = false;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- 3. store (R.out is 16-byte aligned, B is a multiple of 64 KiB)
-    u8* dst = R.out + B;
-    const u32 n = t_hi - B;
-    for (u32 i = tid * 16; i < n; i += SN_THREADS * 16) {
-        if (i + 16 <= n) *(u32x4*)(dst + i) = *(const u32x4*)(s_o + i);
-        else for (u32 k = i; k < n; k++) dst[k] = s_o[k];
-    }
-    // the tile's bytes are in memory: later tiles of the block may read them
-    __threadfence();
+    // every thread waits for its own stores, then the flag goes up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the stores above have been performed at device scope
     __syncthreads();
     if (tid == 0) __hip_atomic_store(tile_done + ot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -2454,7 +2421,7 @@ hipError_t launch_snappy_tiles(hipStream_t st, const u8* src, const Region* regi
                                u32* tile_done) {
     if (n_otiles == 0) return hipSuccess;
     // tile_done: n_otiles flags and the ticket counter behind them, all zero
-    hipLaunchKernelGGL(k_snappy_tiles, dim3(n_otiles), dim3(SN_THREADS), 0, st, src, regions, otile_region, run_tbl, otile_first_run,
+    hipLaunchKernelGGL(k_snappy_ptr, dim3(n_otiles), dim3(SP_THREADS), 0, st, src, regions, otile_region, run_tbl, otile_first_run,
                        totals, status, tile_done, tile_done + n_otiles, n_otiles);
     LAUNCH_CHECK();
     return hipSuccess;

@@ -98,7 +98,7 @@ def test_snappy_files(ctx, p_null):
 
 
 def test_snappy_pages_larger_than_a_tile(ctx):
-    """Pages of several hundred KiB: many 64 KiB output tiles per page, literals that span tiles."""
+    """Pages of several hundred KiB: many output tiles per page, literals that span tiles."""
     rng = np.random.default_rng(44)
     cols = [Column("i", N.INT64, [0]), Column("s", N.BYTE_ARRAY, [1]), Column("z", N.INT32, [1])]
     buf = H.build_file(cols, 120000, 120000, 60000, rng, p_null=0.1, str_len=(4, 30), alphabet=(48, 58), codec=1)
@@ -167,20 +167,22 @@ def _apply(out, length, offset):
         out.append(out[-offset])
 
 
-def test_copies_across_64k_output_tiles(ctx):
-    """Valid snappy that no block-wise encoder writes: copies whose source lies in an earlier 64 KiB tile of
-    the output, copies that run over a tile boundary, far 4-byte offsets.  snappy.Decode reads them all."""
+@pytest.mark.parametrize("first_literal", [32762, 65530])
+def test_copies_across_output_tiles(ctx, first_literal):
+    """Copies whose source lies in an earlier output tile of the decoder (32 KiB each), copies that run over a tile
+    boundary, far 4-byte offsets; with the longer literal, what no encoder of 64 KiB blocks writes.  snappy.Decode
+    reads them all."""
     rng = np.random.default_rng(3)
-    a = bytes(rng.integers(0, 256, 65530, dtype=np.uint8))
+    a = bytes(rng.integers(0, 256, first_literal, dtype=np.uint8))
     b = bytes(rng.integers(0, 256, 10, dtype=np.uint8))
     blocks, wants = [], []
     # source in the previous tile
-    blocks.append(_uvarint(65530 + 10 + 8) + _lit(a) + _lit(b) + _copy(8, 12))
+    blocks.append(_uvarint(first_literal + 10 + 8) + _lit(a) + _lit(b) + _copy(8, 12))
     wants.append(a + b + (a + b)[-12:-4])
     # a copy that starts 6 bytes before the boundary and ends behind it; then copies of its bytes
     out = bytearray(a)
     body = _lit(a)
-    for length, offset, kind in [(40, 1000, 2), (8, 8, 1), (30, 3, 2), (64, 65000, 2), (64, 65536 + 50, 4), (11, 2047, 1)]:
+    for length, offset, kind in [(40, 1000, 2), (8, 8, 1), (30, 3, 2), (64, first_literal - 100, 2), (64, first_literal, 4), (11, 2047, 1)]:
         body += _copy(length, offset, kind)
         _apply(out, length, offset)
     blocks.append(_uvarint(len(out)) + body)
