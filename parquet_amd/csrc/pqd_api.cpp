@@ -21,6 +21,7 @@ struct pqd_ctx {
     hipStream_t stream2 = nullptr;  // side stream of the first pass over the strings
     hipStream_t stream3 = nullptr;  // side stream of the PLAIN value gather
     bool overlap = true;            // PQD_OVERLAP=0 keeps everything on one stream
+    bool str_after_levels = false;  // PQD_STR_AFTER_LEVELS=1: diagnostics, see enqueue_run
     bool graph = false;             // PQD_GRAPH=1 replays chain batches as a captured HIP graph
     std::string err;
     u32 copy_grid = 0x7fffffffu;  // one block per 4 KiB tile; PQD_COPY_GRID caps it (then blocks grid-stride)
@@ -101,6 +102,7 @@ struct pqd_plan {
     hipEvent_t ev_fork = nullptr;  // orders the value gather's side stream after the run start
     hipEvent_t ev_join = nullptr;  // ... the strings' marking pass after their first pass
     hipEvent_t ev_join_copy = nullptr;  // ... and the run's end after the gather
+    hipEvent_t ev_levels = nullptr;     // diagnostics (PQD_STR_AFTER_LEVELS): orders the strings' marking pass behind the level decode
     hipGraphExec_t gexec = nullptr;  // captured run (see pqd_plan_run)
     const u8* gsrc = nullptr;        // the source pointer the graph was captured with
     uint64_t runs = 0;
@@ -166,6 +168,8 @@ int pqd_create(int device, pqd_ctx** out) {
     if (g && atoi(g) > 0) ctx->copy_grid = (u32)atoi(g);
     const char* ov = getenv("PQD_OVERLAP");
     if (ov) ctx->overlap = atoi(ov) != 0;
+    const char* sal = getenv("PQD_STR_AFTER_LEVELS");
+    if (sal) ctx->str_after_levels = atoi(sal) != 0;
     const char* gr = getenv("PQD_GRAPH");
     if (gr) ctx->graph = atoi(gr) != 0;
     *out = ctx;
@@ -229,6 +233,7 @@ void pqd_plan_destroy(pqd_plan* pl) {
     if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
     if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
     if (pl->ev_join_copy) (void)hipEventDestroy(pl->ev_join_copy);
+    if (pl->ev_levels) (void)hipEventDestroy(pl->ev_levels);
     if (pl->gexec) (void)hipGraphExecDestroy(pl->gexec);
     delete pl;
 }
@@ -619,6 +624,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_join_copy, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_levels, hipEventDisableTiming));
     pl->h_chunk_dyn.resize(n_chunks);
     guard.p = nullptr;
     *out = pl;
@@ -657,13 +663,19 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
         HIP_TRY(ctx, launch_chain(sst, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_str_pd, pl->d_status, 0));
         HIP_TRY(ctx, launch_str_page_scan(sst, pl->d_sregions, pl->d_str_chunk_prefix, (u32)pl->str_chunk_prefix.size() - 1,
                                           pl->d_stotals, pl->d_str_pd));
-        HIP_TRY(ctx, launch_chain(sst, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_str_pd, pl->d_status, 1));
-        if (str_early) HIP_TRY(ctx, hipEventRecord(pl->ev_join, sst));
     }
 
     // levels, then everything that only needs them
     if (n_lreg) HIP_TRY(ctx, launch_levels(st, src, pl->lv, pl->lv_tile));
     HIP_TRY(ctx, launch_page_scan(st, pl->d_chunks, n_chunks, pl->d_pages, n_pages, pl->d_page_dyn, pl->d_chunk_dyn, pl->d_status));
+    if (n_sreg) {
+        if (str_early && ctx->str_after_levels) {  // diagnostics: the marking pass behind the level decode, as it was when it took the page offsets from there
+            HIP_TRY(ctx, hipEventRecord(pl->ev_levels, st));
+            HIP_TRY(ctx, hipStreamWaitEvent(sst, pl->ev_levels, 0));
+        }
+        HIP_TRY(ctx, launch_chain(sst, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_str_pd, pl->d_status, 1));
+        if (str_early) HIP_TRY(ctx, hipEventRecord(pl->ev_join, sst));
+    }
     HIP_TRY(ctx, launch_value_index(st, pl->d_chunks, pl->d_pages, pl->d_page_dyn, pl->d_vidx_pages, (u32)pl->vidx_pages.size(), pl->d_lvl_off));
     HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, (u32)pl->bool_pages.size(), pl->n_btiles,
                               pl->d_chunks, pl->d_page_dyn, pl->d_status));
@@ -829,8 +841,9 @@ int pqd_plan_scatter(pqd_plan* pl, size_t c, void* dst_device, size_t dst_bytes)
     if (!dst_device || ((uintptr_t)dst_device & 15) || dst_bytes < n_slots * (u64)w)
         return fail(ctx, PQD_E_ARG, "scatter: destination missing, not 16-byte aligned or too small");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t src_cap = pl->outs[c].cap[strings ? PQD_OUT_OFFSETS : PQD_OUT_VALUES] / (size_t)w;
     HIP_TRY(ctx, launch_scatter(ctx->stream, w, strings, C.validity, C.value_index, strings ? C.offsets : C.values, (u8*)dst_device,
-                                n_slots, (C.n_levels + 63) / 64));
+                                n_slots, (C.n_levels + 63) / 64, (u32)(src_cap < 0xFFFFFFFFull ? src_cap : 0xFFFFFFFFull)));
     return PQD_OK;
 }
 

@@ -191,9 +191,10 @@ hipError_t launch_value_index(hipStream_t st, const ChunkRec* chunks, const Page
 hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids, const u32* btile_prefix,
                         u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn, const int* status);
 // null-mask scatter of one chunk: dense values (width 1, 4 or 8 bytes) or string offsets (offsets = true, width 4,
-// n_slots = levels + 1) to their level slots; dst 16-byte aligned; n_words = 64-bit words of the validity bitmap
+// n_slots = levels + 1) to their level slots; dst 16-byte aligned; n_words = 64-bit words of the validity bitmap;
+// n_src = entries the source array holds (indices at or beyond it are not read)
 hipError_t launch_scatter(hipStream_t st, int width, bool offsets, const u8* validity, const u8* value_index, const u8* values,
-                          u8* dst, u64 n_slots, u64 n_words);
+                          u8* dst, u64 n_slots, u64 n_words, u32 n_src);
 // strings: per-page value and char offsets within the chunk from the first pass's string counts (one wave per
 // string chunk; region_prefix has n_str_chunks + 1 entries); str_pd is indexed by string region
 hipError_t launch_str_page_scan(hipStream_t st, const Region* regions, const u32* region_prefix, u32 n_str_chunks,

@@ -1709,7 +1709,8 @@ __global__ __launch_bounds__(1024) void k_value_index(const ChunkRec* __restrict
 // =====================================================================================
 template <int W, bool OFFSETS>
 __global__ __launch_bounds__(256) void k_scatter(const u64* __restrict__ validity, const u32* __restrict__ value_index,
-                                                 const u8* __restrict__ values, u8* __restrict__ dst, u64 n_slots, u64 n_words) {
+                                                 const u8* __restrict__ values, u8* __restrict__ dst, u64 n_slots, u64 n_words,
+                                                 u32 n_src) {
     constexpr u32 PER = 16 / W;
     const u64 i0 = ((u64)blockIdx.x * 256 + threadIdx.x) * PER;
     if (i0 >= n_slots) return;
@@ -1723,7 +1724,7 @@ __global__ __launch_bounds__(256) void k_scatter(const u64* __restrict__ validit
     for (u32 j = 0; j < PER; j++) {
         const bool on = (bits >> j) & 1;
         if (OFFSETS || on) {
-            if (i0 + j < n_slots) {
+            if (i0 + j < n_slots && vi < n_src) {  // n_src: entries the source array holds (a failed run may leave any index)
                 if (W == 1) o[j >> 2] |= (u32)values[vi] << (8 * (j & 3));
                 else if (W == 4) o[j] = ((const u32*)values)[vi];
                 else { const u64 v = ((const u64*)values)[vi]; o[2 * j] = (u32)v; o[2 * j + 1] = (u32)(v >> 32); }
@@ -2367,17 +2368,17 @@ hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, con
 }
 
 hipError_t launch_scatter(hipStream_t st, int width, bool offsets, const u8* validity, const u8* value_index, const u8* values,
-                          u8* dst, u64 n_slots, u64 n_words) {
+                          u8* dst, u64 n_slots, u64 n_words, u32 n_src) {
     if (n_slots == 0) return hipSuccess;
     const u32 per = 16 / (u32)width;
     const u64 n_thr = (n_slots + per - 1) / per, grid = (n_thr + 255) / 256;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const u64* vb = (const u64*)validity;
     const u32* vx = (const u32*)value_index;
-    if (offsets) hipLaunchKernelGGL((k_scatter<4, true>), dim3((u32)grid), dim3(256), 0, st, vb, vx, values, dst, n_slots, n_words);
-    else if (width == 1) hipLaunchKernelGGL((k_scatter<1, false>), dim3((u32)grid), dim3(256), 0, st, vb, vx, values, dst, n_slots, n_words);
-    else if (width == 4) hipLaunchKernelGGL((k_scatter<4, false>), dim3((u32)grid), dim3(256), 0, st, vb, vx, values, dst, n_slots, n_words);
-    else if (width == 8) hipLaunchKernelGGL((k_scatter<8, false>), dim3((u32)grid), dim3(256), 0, st, vb, vx, values, dst, n_slots, n_words);
+    if (offsets) hipLaunchKernelGGL((k_scatter<4, true>), dim3((u32)grid), dim3(256), 0, st, vb, vx, values, dst, n_slots, n_words, n_src);
+    else if (width == 1) hipLaunchKernelGGL((k_scatter<1, false>), dim3((u32)grid), dim3(256), 0, st, vb, vx, values, dst, n_slots, n_words, n_src);
+    else if (width == 4) hipLaunchKernelGGL((k_scatter<4, false>), dim3((u32)grid), dim3(256), 0, st, vb, vx, values, dst, n_slots, n_words, n_src);
+    else if (width == 8) hipLaunchKernelGGL((k_scatter<8, false>), dim3((u32)grid), dim3(256), 0, st, vb, vx, values, dst, n_slots, n_words, n_src);
     else return hipErrorInvalidValue;
     LAUNCH_CHECK();
     return hipSuccess;
