@@ -821,3 +821,36 @@ def test_value_index_scatters_dense_values_to_their_rows(ctx):
         assert np.array_equal(dense[vi[rows[:500] // 64] + below], vals[rows[:500]])
     finally:
         plan.close()
+
+
+@pytest.mark.parametrize("env", [{"PQD_OVERLAP": "0"}, {"PQD_STR_AFTER_LEVELS": "1"}, {"PQD_OVERLAP": "0", "PQD_GRAPH": "1"}])
+def test_stream_schedules_give_the_same_results(monkeypatch, env):
+    """The decoder's launches on one stream (PQD_OVERLAP=0) and with the strings' marking pass behind the level decode:
+    every schedule of the same kernels decodes the same arrays, repeated runs included."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = R.Context(0)
+    try:
+        rng = np.random.default_rng(78)
+        cols = [Column("a", N.INT32, [1]), Column("s", N.BYTE_ARRAY, [1]), Column("t", N.BYTE_ARRAY, [0]), Column("b", N.BOOLEAN, [1]),
+                Column("d", N.DOUBLE, [0]), Column("r.x", N.INT64, [2, 1]), Column("r.s", N.BYTE_ARRAY, [2, 1])]
+        buf = H.build_file(cols, 30000, 15000, 4000, rng, p_null=0.2, str_len=(0, 40), alphabet=(97, 123))
+        H.check_file(buf, c)
+        pf = R.ParquetFile(buf)
+        chunks, nc, pages, npg = pf.descriptors(0, pf.num_row_groups)
+        plan = R.Plan(c, chunks, nc, pages, npg, pf.address, pf.size)
+        d_src = N.decode.pqd_device_alloc(c.handle, pf.size)
+        try:
+            assert N.decode.pqd_copy_to_device(c.handle, d_src, pf.address, pf.size) == 0
+            for _ in range(3):
+                plan.run(d_src)
+            plan.sync()
+            o = H.oracle_file(buf, pf)
+            per_rg = nc // pf.num_row_groups
+            for k in range(nc):
+                H.assert_chunk_equal(o[(k // per_rg, pf.columns[chunks[k].column][0])], plan.column(k), key=k)
+        finally:
+            N.decode.pqd_device_free(c.handle, d_src)
+            plan.close()
+    finally:
+        c.close()
