@@ -60,7 +60,7 @@ struct pqd_plan {
     std::vector<LvTile> lv_order;  // launch order of the level super-tiles
     std::vector<u32> stile_chain_prefix, sgroup_prefix, ssuper_prefix;
     std::vector<Seg> segs;
-    std::vector<u32> seg_blk_prefix;
+    std::vector<u32> seg_blk_prefix, seg_grp;
     std::vector<u32> bool_pages, btile_prefix, row_chunks, rtile_prefix;
     std::vector<u32> stile_region;  // region of every string chain tile
     std::vector<u32> vidx_pages;    // pages of the chunks that have definition levels
@@ -76,7 +76,7 @@ struct pqd_plan {
     Region *d_lregions = nullptr, *d_sregions = nullptr;
     u32* d_stile_chain_prefix = nullptr;
     u32 *d_sgroup_prefix = nullptr, *d_ssuper_prefix = nullptr;
-    Seg* d_segs = nullptr; u32* d_seg_blk_prefix = nullptr;
+    Seg* d_segs = nullptr; u32* d_seg_blk_prefix = nullptr; u32* d_seg_grp = nullptr;
     u32 *d_bool_pages = nullptr, *d_btile_prefix = nullptr;
     u32 *d_row_chunks = nullptr, *d_rtile_prefix = nullptr;
     ExitRec *d_sexit = nullptr, *d_sgexit = nullptr;
@@ -511,11 +511,17 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t zero_end = ap.total;
     // the copy segment tables depend on output addresses → placed last, sized now
     size_t n_segs = 0;
+    u64 max_blocks = 0;  // upper bound of the gather's blocks: a segment's destination may be misaligned by up to 15 bytes
     for (size_t c = 0; c < n_chunks; c++)
         if (pl->chunks[c].width_bytes)
-            for (u32 k = 0; k < pl->chunks[c].n_pages; k++) n_segs += pl->pages[pl->chunks[c].first_page + k].val_len > 0;
+            for (u32 k = 0; k < pl->chunks[c].n_pages; k++) {
+                const u32 vl = pl->pages[pl->chunks[c].first_page + k].val_len;
+                n_segs += vl > 0;
+                if (vl) max_blocks += ((u64)vl + 15 + CP_BLK - 1) / CP_BLK;
+            }
     const size_t o_segs = ap.take(n_segs * sizeof(Seg));
     const size_t o_segp = ap.take((n_segs + 1) * 4);
+    const size_t o_segg = ap.take((size_t)(max_blocks / CP_GRP + 2) * 4);  // segment of every CP_GRP-th block
 
     pl->arena_bytes = ap.total;
     hipError_t e = hipMalloc((void**)&pl->arena, pl->arena_bytes);
@@ -568,6 +574,15 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         }
     }
     pl->n_copy_blocks = pl->seg_blk_prefix.back();
+    {   // where the owner search of a block starts: the segment that holds block g * CP_GRP
+        u32 sidx = 0;
+        for (u64 b = 0; b < pl->n_copy_blocks; b += CP_GRP) {
+            while (pl->seg_blk_prefix[sidx + 1] <= b) sidx++;
+            pl->seg_grp.push_back(sidx);
+        }
+        pl->seg_grp.push_back(pl->segs.empty() ? 0u : (u32)pl->segs.size() - 1);  // closes the last group
+        if (pl->seg_grp.size() > max_blocks / CP_GRP + 2) return fail(ctx, PQD_E_HIP, "copy block table larger than planned");
+    }
 
     pl->d_chunks = (ChunkRec*)(A + o_chunks); pl->d_pages = (PageRec*)(A + o_pages);
     pl->d_lregions = (Region*)(A + o_lreg); pl->d_sregions = (Region*)(A + o_sreg);
@@ -585,7 +600,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->d_chunk_dyn = (ChunkDyn*)(A + o_cdyn);
     pl->d_stile_entry = (TileEntry*)(A + o_ste);
     pl->d_page_dyn = (PageDyn*)(A + o_pdyn); pl->d_status = (int*)(A + o_status);
-    pl->d_segs = (Seg*)(A + o_segs); pl->d_seg_blk_prefix = (u32*)(A + o_segp);
+    pl->d_segs = (Seg*)(A + o_segs); pl->d_seg_blk_prefix = (u32*)(A + o_segp); pl->d_seg_grp = (u32*)(A + o_segg);
     pl->ff_begin = A + o_ff; pl->ff_bytes = ff_end - o_ff;
     pl->zero_begin = A + o_zero; pl->zero_bytes = zero_end - o_zero;
 
@@ -618,6 +633,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if ((rc = upload(ctx, pl->d_rtile_prefix, pl->rtile_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_segs, pl->segs))) return rc;
     if ((rc = upload(ctx, pl->d_seg_blk_prefix, pl->seg_blk_prefix))) return rc;
+    if ((rc = upload(ctx, pl->d_seg_grp, pl->seg_grp))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& set : pl->ev)
         for (hipEvent_t& e : set) HIP_TRY(ctx, hipEventCreate(&e));
@@ -653,7 +669,7 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     if (copy_side || str_early) HIP_TRY(ctx, hipEventRecord(pl->ev_fork, st));
     if (copy_side) HIP_TRY(ctx, hipStreamWaitEvent(cst, pl->ev_fork, 0));
     if (ev_c0) HIP_TRY(ctx, hipEventRecord(ev_c0, cst));
-    HIP_TRY(ctx, launch_copy(cst, src, pl->d_segs, pl->d_seg_blk_prefix, (u32)pl->segs.size(), pl->n_copy_blocks, ctx->copy_grid));
+    HIP_TRY(ctx, launch_copy(cst, src, pl->d_segs, pl->d_seg_blk_prefix, pl->d_seg_grp, (u32)pl->segs.size(), pl->n_copy_blocks, ctx->copy_grid));
     if (ev_c1) HIP_TRY(ctx, hipEventRecord(ev_c1, cst));
     if (copy_side) HIP_TRY(ctx, hipEventRecord(pl->ev_join_copy, cst));
     // strings, both passes: a page's place in the chunk's offsets and chars follows from the string counts of the

@@ -24,6 +24,7 @@ constexpr int PT_BOOLEAN = 0, PT_BYTE_ARRAY = 6;
 constexpr int CP_THREADS = 256;
 constexpr int CP_UNROLL = 1;
 constexpr u32 CP_BLK = CP_THREADS * 16 * CP_UNROLL;  // bytes per block (4 KiB): many small blocks beat a grid-stride loop here
+constexpr u32 CP_GRP = 256;  // the planner tabulates the segment of every CP_GRP-th block: a block finds its own from there in a step or two
 
 struct Seg {
     u64 src_off;  // byte offset in the source buffer
@@ -107,8 +108,8 @@ struct ChunkDyn {
 struct RowTile { u32 rows, vals; u64 row_base, val_base; };
 
 // ---- launchers -----------------------------------------------------------------------------
-hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32* blk_prefix, u32 n_segs, u32 n_blocks,
-                       u32 max_grid);
+hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32* blk_prefix, const u32* blk_grp, u32 n_segs,
+                       u32 n_blocks, u32 max_grid);
 // strings: which positions of a chain tile are plausible string starts (see entry_slot in pqd_kernels.hip)
 struct StrIndex {
     const unsigned short* cand;  // n_tiles * CH_E_STRINGS: tile offsets of the first plausible positions, ascending, 0xFFFF = none

@@ -43,10 +43,18 @@ static __device__ __forceinline__ u32 find_owner(const u32* __restrict__ prefix,
 // alignment).  Each wave instruction covers 1 KiB of contiguous memory on both sides.
 // =====================================================================================
 __global__ __launch_bounds__(CP_THREADS) void k_copy(const u8* __restrict__ src_base, const Seg* __restrict__ segs,
-                                                     const u32* __restrict__ blk_prefix, u32 n_segs, u32 n_blocks) {
+                                                     const u32* __restrict__ blk_prefix, const u32* __restrict__ blk_grp,
+                                                     u32 n_segs, u32 n_blocks) {
     const u32 tid = threadIdx.x;
     for (u32 b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        const u32 s = find_owner(blk_prefix, n_segs, b);
+        // the segment of block b lies between those of blocks b / CP_GRP * CP_GRP and the next multiple, which a
+        // table holds.  Pages are thousands of blocks long, so the two are mostly the same segment and the search
+        // ends at once (a binary search over all segments is ten dependent scalar loads, a third of a copy wave's life)
+        u32 s = blk_grp[b / CP_GRP], s_hi = blk_grp[b / CP_GRP + 1];
+        while (s < s_hi) {
+            const u32 mid = (s + s_hi + 1) >> 1;
+            if (blk_prefix[mid] <= b) s = mid; else s_hi = mid - 1;
+        }
         const Seg sg = segs[s];
         const u32 bi = b - blk_prefix[s];
         const u64 a = (u64)sg.dst & 15;            // destination misalignment
@@ -2253,11 +2261,11 @@ __global__ __launch_bounds__(1024) void k_rows_scan(const ChunkRec* __restrict__
 // =====================================================================================
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
-hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32* blk_prefix, u32 n_segs, u32 n_blocks,
-                       u32 max_grid) {
+hipError_t launch_copy(hipStream_t st, const u8* src, const Seg* segs, const u32* blk_prefix, const u32* blk_grp, u32 n_segs,
+                       u32 n_blocks, u32 max_grid) {
     if (n_blocks == 0) return hipSuccess;
     const u32 grid = n_blocks < max_grid ? n_blocks : max_grid;
-    hipLaunchKernelGGL(k_copy, dim3(grid), dim3(CP_THREADS), 0, st, src, segs, blk_prefix, n_segs, n_blocks);
+    hipLaunchKernelGGL(k_copy, dim3(grid), dim3(CP_THREADS), 0, st, src, segs, blk_prefix, blk_grp, n_segs, n_blocks);
     LAUNCH_CHECK();
     return hipSuccess;
 }
