@@ -62,6 +62,7 @@ struct pqd_plan {
     std::vector<Seg> segs;
     std::vector<u32> seg_blk_prefix, seg_grp;
     std::vector<u32> bool_pages, btile_prefix, row_chunks, rtile_prefix;
+    std::vector<u32> btile_owner, rtile_owner;  // per tile: its index into bool_pages / row_chunks (no search on the device)
     std::vector<u32> stile_region;  // region of every string chain tile
     std::vector<u32> vidx_pages;    // pages of the chunks that have definition levels
     std::vector<u64> page_lvl_off;  // level index of every page's first level within its chunk
@@ -79,6 +80,7 @@ struct pqd_plan {
     Seg* d_segs = nullptr; u32* d_seg_blk_prefix = nullptr; u32* d_seg_grp = nullptr;
     u32 *d_bool_pages = nullptr, *d_btile_prefix = nullptr;
     u32 *d_row_chunks = nullptr, *d_rtile_prefix = nullptr;
+    u32 *d_btile_owner = nullptr, *d_rtile_owner = nullptr;
     ExitRec *d_sexit = nullptr, *d_sgexit = nullptr;
     TileEntry *d_stile_entry = nullptr, *d_sgroup_entry = nullptr;
     ChainArgs schain = {};
@@ -457,6 +459,10 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         pl->stile_region.insert(pl->stile_region.end(), pl->stile_chain_prefix[r + 1] - pl->stile_chain_prefix[r], (u32)r);
     pl->n_btiles = pl->btile_prefix.back();
     pl->n_rtiles = pl->rtile_prefix.back();
+    for (size_t k = 0; k + 1 < pl->btile_prefix.size(); k++)
+        pl->btile_owner.insert(pl->btile_owner.end(), pl->btile_prefix[k + 1] - pl->btile_prefix[k], (u32)k);
+    for (size_t k = 0; k + 1 < pl->rtile_prefix.size(); k++)
+        pl->rtile_owner.insert(pl->rtile_owner.end(), pl->rtile_prefix[k + 1] - pl->rtile_prefix[k], (u32)k);
 
     // static tables
     const size_t o_chunks = ap.take(n_chunks * sizeof(ChunkRec));
@@ -474,6 +480,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_btp = ap.take(pl->btile_prefix.size() * 4);
     const size_t o_rc = ap.take(pl->row_chunks.size() * 4);
     const size_t o_rtp = ap.take(pl->rtile_prefix.size() * 4);
+    const size_t o_bto = ap.take(pl->btile_owner.size() * 4), o_rto = ap.take(pl->rtile_owner.size() * 4);
     // scratch
     const size_t o_sexit = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * sizeof(StrExit));
     const size_t o_scp = ap.take((size_t)pl->n_stiles_chain * CH_E_STRINGS * 16);
@@ -593,6 +600,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->d_sgroup_entry = (TileEntry*)(A + o_sge);
     pl->d_bool_pages = (u32*)(A + o_bp); pl->d_btile_prefix = (u32*)(A + o_btp);
     pl->d_row_chunks = (u32*)(A + o_rc); pl->d_rtile_prefix = (u32*)(A + o_rtp);
+    pl->d_btile_owner = (u32*)(A + o_bto); pl->d_rtile_owner = (u32*)(A + o_rto);
     pl->d_sexit = (ExitRec*)(A + o_sexit);
     pl->d_stotals = (RegionTotal*)(A + o_stot);
     pl->d_str_chunk_prefix = (u32*)(A + o_scpf); pl->d_str_pd = (PageDyn*)(A + o_spd);
@@ -631,6 +639,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if ((rc = upload(ctx, pl->d_btile_prefix, pl->btile_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_row_chunks, pl->row_chunks))) return rc;
     if ((rc = upload(ctx, pl->d_rtile_prefix, pl->rtile_prefix))) return rc;
+    if ((rc = upload(ctx, pl->d_btile_owner, pl->btile_owner))) return rc;
+    if ((rc = upload(ctx, pl->d_rtile_owner, pl->rtile_owner))) return rc;
     if ((rc = upload(ctx, pl->d_segs, pl->segs))) return rc;
     if ((rc = upload(ctx, pl->d_seg_blk_prefix, pl->seg_blk_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_seg_grp, pl->seg_grp))) return rc;
@@ -693,9 +703,9 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
         if (str_early) HIP_TRY(ctx, hipEventRecord(pl->ev_join, sst));
     }
     HIP_TRY(ctx, launch_value_index(st, pl->d_chunks, pl->d_pages, pl->d_page_dyn, pl->d_vidx_pages, (u32)pl->vidx_pages.size(), pl->d_lvl_off));
-    HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, (u32)pl->bool_pages.size(), pl->n_btiles,
+    HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, pl->d_btile_owner, (u32)pl->bool_pages.size(), pl->n_btiles,
                               pl->d_chunks, pl->d_page_dyn, pl->d_status));
-    HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
+    HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_rtile_owner, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
                              pl->d_row_tiles, pl->d_chunk_dyn));
     if (n_sreg) {
         if (str_early) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join, 0));

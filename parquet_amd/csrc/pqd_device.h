@@ -190,7 +190,8 @@ hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks
 hipError_t launch_value_index(hipStream_t st, const ChunkRec* chunks, const PageRec* pages, const PageDyn* page_dyn,
                               const u32* page_ids, u32 n_pages, const u64* page_lvl_off);
 hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids, const u32* btile_prefix,
-                        u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn, const int* status);
+                        const u32* btile_owner, u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn,
+                        const int* status);
 // null-mask scatter of one chunk: dense values (width 1, 4 or 8 bytes) or string offsets (offsets = true, width 4,
 // n_slots = levels + 1) to their level slots; dst 16-byte aligned; n_words = 64-bit words of the validity bitmap;
 // n_src = entries the source array holds (indices at or beyond it are not read)
@@ -202,8 +203,8 @@ hipError_t launch_str_page_scan(hipStream_t st, const Region* regions, const u32
                                 const RegionTotal* totals, PageDyn* str_pd);
 hipError_t launch_str_check(hipStream_t st, const PageRec* pages, const ChunkRec* chunks, const PageDyn* page_dyn,
                             const Region* regions, u32 n_regions, const RegionTotal* totals, int* status);
-hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_prefix, const u32* chunk_ids, u32 n_rchunks,
-                       u32 n_rtiles, RowTile* tiles, ChunkDyn* chunk_dyn);
+hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_prefix, const u32* rtile_owner, const u32* chunk_ids,
+                       u32 n_rchunks, u32 n_rtiles, RowTile* tiles, ChunkDyn* chunk_dyn);
 
 // snappy: decode tiles of SN_T output bytes from the element records (otile_region / otile_first_run have one
 // spare entry each); every Region.out must be 16-byte aligned; tile_done: n_otiles + 1 words, all zero (one flag

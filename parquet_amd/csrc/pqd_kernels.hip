@@ -1751,11 +1751,11 @@ __global__ __launch_bounds__(256) void k_scatter(const u64* __restrict__ validit
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_bools(const u8* __restrict__ src_base, const PageRec* __restrict__ pages,
                                                const u32* __restrict__ page_ids, const u32* __restrict__ btile_prefix,
-                                               u32 n_bpages, const ChunkRec* __restrict__ chunks,
+                                               const u32* __restrict__ btile_owner, u32 n_bpages, const ChunkRec* __restrict__ chunks,
                                                const PageDyn* __restrict__ page_dyn, const int* __restrict__ status) {
     if (status[0]) return;  // an earlier kernel found the batch corrupt: value counts and offsets are not to be trusted
     const u32 bt = blockIdx.x;
-    const u32 k = find_owner(btile_prefix, n_bpages, bt);
+    const u32 k = btile_owner[bt];  // which bool page the tile belongs to (a table: no search over the prefix)
     const u32 pg = page_ids[k];
     const PageRec P = pages[pg];
     const ChunkRec C = chunks[P.chunk];
@@ -2128,12 +2128,13 @@ __global__ void k_level_block_sizes(const u8* __restrict__ src, const PageRec* _
 // =====================================================================================
 // Row starts and non-null levels of every tile of RT levels: one wave per tile, 64 levels per lane from the bitmaps.
 __global__ __launch_bounds__(256) void k_rows_count(const ChunkRec* __restrict__ chunks, const u32* __restrict__ rtile_prefix,
+                                                    const u32* __restrict__ rtile_owner,
                                                     const u32* __restrict__ chunk_ids, u32 n_rchunks, u32 n_rtiles,
                                                     RowTile* __restrict__ tiles) {
     static_assert(RT == 64 * 64, "one 64-bit word of each bitmap per lane");
     const u32 lane = threadIdx.x & 63, rt = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rt >= n_rtiles) return;
-    const u32 k = find_owner(rtile_prefix, n_rchunks, rt);
+    const u32 k = rtile_owner[rt];  // which repeated chunk the tile belongs to (a table: no search over the prefix)
     const ChunkRec C = chunks[chunk_ids[k]];
     const u64 n = C.n_levels;
     const u64 i0 = (u64)(rt - rtile_prefix[k]) * RT + lane * 64;
@@ -2154,11 +2155,12 @@ __global__ __launch_bounds__(256) void k_rows_count(const ChunkRec* __restrict__
 
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunks, const u32* __restrict__ rtile_prefix,
+                                              const u32* __restrict__ rtile_owner,
                                               const u32* __restrict__ chunk_ids, u32 n_rchunks,
                                               RowTile* __restrict__ tiles) {
     __shared__ u32 s_rows[4], s_vals[4];
     const u32 rt = blockIdx.x;
-    const u32 k = find_owner(rtile_prefix, n_rchunks, rt);
+    const u32 k = rtile_owner[rt];  // which repeated chunk the tile belongs to (a table: no search over the prefix)
     const ChunkRec C = chunks[chunk_ids[k]];
     const u64 n = C.n_levels;
     const u64 i0 = (u64)(rt - rtile_prefix[k]) * RT + threadIdx.x * 16;
@@ -2368,9 +2370,11 @@ hipError_t launch_value_index(hipStream_t st, const ChunkRec* chunks, const Page
 }
 
 hipError_t launch_bools(hipStream_t st, const u8* src, const PageRec* pages, const u32* page_ids, const u32* btile_prefix,
-                        u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn, const int* status) {
+                        const u32* btile_owner, u32 n_bpages, u32 n_btiles, const ChunkRec* chunks, const PageDyn* page_dyn,
+                        const int* status) {
     if (n_btiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_bools, dim3(n_btiles), dim3(256), 0, st, src, pages, page_ids, btile_prefix, n_bpages, chunks, page_dyn, status);
+    hipLaunchKernelGGL(k_bools, dim3(n_btiles), dim3(256), 0, st, src, pages, page_ids, btile_prefix, btile_owner, n_bpages, chunks, page_dyn,
+                       status);
     LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -2409,17 +2413,18 @@ hipError_t launch_str_check(hipStream_t st, const PageRec* pages, const ChunkRec
     return hipSuccess;
 }
 
-hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_prefix, const u32* chunk_ids, u32 n_rchunks,
-                       u32 n_rtiles, RowTile* tiles, ChunkDyn* chunk_dyn) {
+hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_prefix, const u32* rtile_owner, const u32* chunk_ids,
+                       u32 n_rchunks, u32 n_rtiles, RowTile* tiles, ChunkDyn* chunk_dyn) {
     if (n_rchunks == 0) return hipSuccess;
     if (n_rtiles) {
-        hipLaunchKernelGGL(k_rows_count, dim3((n_rtiles + 3) / 4), dim3(256), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, n_rtiles, tiles);
+        hipLaunchKernelGGL(k_rows_count, dim3((n_rtiles + 3) / 4), dim3(256), 0, st, chunks, rtile_prefix, rtile_owner, chunk_ids, n_rchunks,
+                           n_rtiles, tiles);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_rows_scan, dim3(n_rchunks), dim3(1024), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles, chunk_dyn);
     LAUNCH_CHECK();
     if (n_rtiles) {
-        hipLaunchKernelGGL((k_rows<true>), dim3(n_rtiles), dim3(256), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles);
+        hipLaunchKernelGGL((k_rows<true>), dim3(n_rtiles), dim3(256), 0, st, chunks, rtile_prefix, rtile_owner, chunk_ids, n_rchunks, tiles);
         LAUNCH_CHECK();
     }
     return hipSuccess;
