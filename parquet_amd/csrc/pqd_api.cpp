@@ -104,7 +104,7 @@ struct pqd_plan {
     hipEvent_t ev_fork = nullptr;  // orders the value gather's side stream after the run start
     hipEvent_t ev_join = nullptr;  // ... the strings' marking pass after their first pass
     hipEvent_t ev_join_copy = nullptr;  // ... and the run's end after the gather
-    hipEvent_t ev_levels = nullptr;     // diagnostics (PQD_STR_AFTER_LEVELS): orders the strings' marking pass behind the level decode
+    hipEvent_t ev_levels = nullptr;     // the page scan is done: value index on the side stream; diagnostics (PQD_STR_AFTER_LEVELS)
     hipGraphExec_t gexec = nullptr;  // captured run (see pqd_plan_run)
     const u8* gsrc = nullptr;        // the source pointer the graph was captured with
     uint64_t runs = 0;
@@ -702,7 +702,16 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
         HIP_TRY(ctx, launch_chain(sst, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_str_pd, pl->d_status, 1));
         if (str_early) HIP_TRY(ctx, hipEventRecord(pl->ev_join, sst));
     }
-    HIP_TRY(ctx, launch_value_index(st, pl->d_chunks, pl->d_pages, pl->d_page_dyn, pl->d_vidx_pages, (u32)pl->vidx_pages.size(), pl->d_lvl_off));
+    // The value index needs the page scan only.  In a batch without strings their stream is idle: the index runs there,
+    // beside the bools and the row offsets (nested columns: three launches shorter on the main stream).
+    const bool vidx_side = ctx->overlap && !n_sreg && n_lreg && !pl->row_chunks.empty();
+    if (vidx_side) {
+        HIP_TRY(ctx, hipEventRecord(pl->ev_levels, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, pl->ev_levels, 0));
+    }
+    HIP_TRY(ctx, launch_value_index(vidx_side ? ctx->stream2 : st, pl->d_chunks, pl->d_pages, pl->d_page_dyn, pl->d_vidx_pages,
+                                    (u32)pl->vidx_pages.size(), pl->d_lvl_off));
+    if (vidx_side) HIP_TRY(ctx, hipEventRecord(pl->ev_join, ctx->stream2));
     HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, pl->d_btile_owner, (u32)pl->bool_pages.size(), pl->n_btiles,
                               pl->d_chunks, pl->d_page_dyn, pl->d_status));
     HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_rtile_owner, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
@@ -711,6 +720,7 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
         if (str_early) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join, 0));
         HIP_TRY(ctx, launch_str_check(st, pl->d_pages, pl->d_chunks, pl->d_page_dyn, pl->d_sregions, n_sreg, pl->d_stotals, pl->d_status));
     }
+    if (vidx_side) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join, 0));
     if (copy_side) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join_copy, 0));
     return PQD_OK;
 }

@@ -823,10 +823,12 @@ def test_value_index_scatters_dense_values_to_their_rows(ctx):
         plan.close()
 
 
-@pytest.mark.parametrize("env", [{"PQD_OVERLAP": "0"}, {"PQD_STR_AFTER_LEVELS": "1"}, {"PQD_OVERLAP": "0", "PQD_GRAPH": "1"}])
-def test_stream_schedules_give_the_same_results(monkeypatch, env):
-    """The decoder's launches on one stream (PQD_OVERLAP=0) and with the strings' marking pass behind the level decode:
-    every schedule of the same kernels decodes the same arrays, repeated runs included."""
+@pytest.mark.parametrize("with_strings", [True, False])
+@pytest.mark.parametrize("env", [{}, {"PQD_OVERLAP": "0"}, {"PQD_STR_AFTER_LEVELS": "1"}, {"PQD_GRAPH": "1"}, {"PQD_OVERLAP": "0", "PQD_GRAPH": "1"}])
+def test_stream_schedules_give_the_same_results(monkeypatch, env, with_strings):
+    """The decoder's launches on its three streams, on one stream (PQD_OVERLAP=0), with the strings' marking pass behind the
+    level decode and replayed from a captured graph: every schedule of the same kernels decodes the same arrays,
+    repeated runs included."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     c = R.Context(0)
@@ -834,6 +836,8 @@ def test_stream_schedules_give_the_same_results(monkeypatch, env):
         rng = np.random.default_rng(78)
         cols = [Column("a", N.INT32, [1]), Column("s", N.BYTE_ARRAY, [1]), Column("t", N.BYTE_ARRAY, [0]), Column("b", N.BOOLEAN, [1]),
                 Column("d", N.DOUBLE, [0]), Column("r.x", N.INT64, [2, 1]), Column("r.s", N.BYTE_ARRAY, [2, 1])]
+        if not with_strings:  # a batch without strings runs the value index on their stream
+            cols = [c for c in cols if c.phys_type != N.BYTE_ARRAY]
         buf = H.build_file(cols, 30000, 15000, 4000, rng, p_null=0.2, str_len=(0, 40), alphabet=(97, 123))
         H.check_file(buf, c)
         pf = R.ParquetFile(buf)
