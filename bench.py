@@ -426,6 +426,7 @@ def main():
                                  "note": "runs beside the level and string kernels on a stream of its own, so its launch spans most of the step"},
             },
             "device_ms_per_step_events": round(step_ms, 4),
+            "string_chunks_through_two_passes": ld.plan.string_fallbacks(),
             "setup_seconds": round(t_build, 1),
         }
         if world == 1 and not args.no_cpu_baseline:  # the CPU legs are timed on a single-GPU run only

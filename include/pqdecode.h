@@ -162,6 +162,12 @@ int64_t pqd_plan_fetch(pqd_plan* plan, size_t chunk, pqd_output which, void* dst
  * (n_levels + 1) * 4) bytes.  Queued on the decoder's stream behind the last run; pqd_plan_sync waits for it. */
 int pqd_plan_scatter(pqd_plan* plan, size_t chunk, void* dst_device, size_t dst_bytes);
 
+/* Diagnostics: BYTE_ARRAY column chunks of the last synced run that the single pass over the string bytes gave up and
+ * the exact two-pass kernels decoded instead (contents whose bytes look like length prefixes, corrupt pages).  The
+ * results are the same either way; a large number explains a slow run.  0 when PQD_STR_PATH=twopass sends every chunk
+ * through the two passes. */
+int64_t pqd_plan_string_fallbacks(pqd_plan* plan);
+
 /* Diagnostics: when the plan was created with PQD_LV_STAMPS set in the environment, the level kernel of the
  * last run left 16 wall-clock stamps (100 MHz) per workgroup; copies them to `dst` and returns the bytes
  * (0 when the plan has none). */

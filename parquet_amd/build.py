@@ -32,9 +32,24 @@ def build_all(force=False):
     os.makedirs(LIB, exist_ok=True)
     decode = os.path.join(LIB, "libpqdecode.so")
     if force or _stale(decode, DECODE_DEPS):
+        # one object per source, stale ones compiled side by side (objects live in lib/obj, git-ignored like the .so)
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-              "-Wno-unused-function", "-o", decode] + DECODE_SOURCES + ["-ldl", "-lpthread"])
+        objdir = os.path.join(LIB, "obj")
+        os.makedirs(objdir, exist_ok=True)
+        headers = [d for d in DECODE_DEPS if d not in DECODE_SOURCES]
+        jobs, objs = [], []
+        for src in DECODE_SOURCES:
+            obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+            objs.append(obj)
+            deps = [src] + headers + (["pqd_levels.hip"] if src == "pqd_levels_4k.hip" else [])
+            if force or _stale(obj, deps):
+                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
+                print("+", " ".join(cmd), flush=True)
+                jobs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+        for cmd, job in jobs:
+            if job.wait() != 0:
+                raise subprocess.CalledProcessError(job.returncode, cmd)
+        _run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", decode] + objs + ["-ldl", "-lpthread"])
     synth = os.path.join(LIB, "libpqsynth.so")
     if force or _stale(synth, SYNTH_DEPS):
         _run([os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", synth] + SYNTH_SOURCES)

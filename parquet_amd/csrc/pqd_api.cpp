@@ -22,6 +22,7 @@ struct pqd_ctx {
     hipStream_t stream3 = nullptr;  // side stream of the PLAIN value gather
     bool overlap = true;            // PQD_OVERLAP=0 keeps everything on one stream
     bool str_after_levels = false;  // PQD_STR_AFTER_LEVELS=1: diagnostics, see enqueue_run
+    bool str_fused = true;          // PQD_STR_PATH=twopass: every string chunk through the two passes (the single pass's fallback)
     bool graph = false;             // PQD_GRAPH=1 replays chain batches as a captured HIP graph
     std::string err;
     u32 copy_grid = 0x7fffffffu;  // one block per 4 KiB tile; PQD_COPY_GRID caps it (then blocks grid-stride)
@@ -64,6 +65,7 @@ struct pqd_plan {
     std::vector<u32> bool_pages, btile_prefix, row_chunks, rtile_prefix;
     std::vector<u32> btile_owner, rtile_owner;  // per tile: its index into bool_pages / row_chunks (no search on the device)
     std::vector<u32> stile_region;  // region of every string chain tile
+    std::vector<u32> sunit_region, sunit_order;  // single string pass: region of every unit; launch order of the units
     std::vector<u32> vidx_pages;    // pages of the chunks that have definition levels
     std::vector<u64> page_lvl_off;  // level index of every page's first level within its chunk
     u32* d_vidx_pages = nullptr; u64* d_lvl_off = nullptr;
@@ -112,6 +114,7 @@ struct pqd_plan {
     int last_status = 0;
     std::vector<ChunkDyn> h_chunk_dyn;
     int h_status[4] = {0, 0, 0, 0};
+    std::vector<u32> h_str_failed;  // per BYTE_ARRAY chunk: given up by the single pass in the last synced run
 };
 
 namespace {
@@ -172,6 +175,8 @@ int pqd_create(int device, pqd_ctx** out) {
     if (ov) ctx->overlap = atoi(ov) != 0;
     const char* sal = getenv("PQD_STR_AFTER_LEVELS");
     if (sal) ctx->str_after_levels = atoi(sal) != 0;
+    const char* sp = getenv("PQD_STR_PATH");
+    if (sp) ctx->str_fused = strcmp(sp, "twopass") != 0;
     const char* gr = getenv("PQD_GRAPH");
     if (gr) ctx->graph = atoi(gr) != 0;
     *out = ctx;
@@ -392,9 +397,13 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         v.push_back((u32)nv);
     };
     bool ovf = false;
+    u32 str_chunk_unit0 = 0;  // first unit (single string pass) of the BYTE_ARRAY chunk being planned
     for (size_t c = 0; c < n_chunks; c++) {
         const ChunkRec& C = pl->chunks[c];
-        if (C.phys_type == PQD_BYTE_ARRAY) pl->str_chunk_prefix.push_back((u32)pl->sregions.size());
+        if (C.phys_type == PQD_BYTE_ARRAY) {
+            pl->str_chunk_prefix.push_back((u32)pl->sregions.size());
+            str_chunk_unit0 = (u32)pl->sunit_region.size();
+        }
         for (u32 k = 0; k < C.n_pages; k++) {
             const u32 pi = C.first_page + k;
             const PageRec& P = pl->pages[pi];
@@ -434,6 +443,13 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                 R.n_out = P.num_values;
                 R.page = pi;
                 R.count_level = ERR_POS;
+                // single pass (k_str_fused): ranks and char positions are the chunk's, not the page's
+                R.count_level = (u32)pl->sunit_region.size();  // first unit of the page
+                R.lv_base = str_chunk_unit0;                    // first unit of the chunk
+                R.run_base = val_stream_off[pi];
+                pl->sunit_region.insert(pl->sunit_region.end(), ((size_t)P.val_len + SF_TPU * CH_T - 1) / (SF_TPU * CH_T), (u32)pl->sregions.size());
+                R.width = (u32)(C.n_levels < 0xFFFFFFFFull ? C.n_levels : 0xFFFFFFFFull);
+                R.otile_base = (u32)pl->str_chunk_prefix.size() - 1;
                 pl->sregions.push_back(R);
                 push_prefix(pl->stile_chain_prefix, ((u64)P.val_len + CH_T - 1) / CH_T, ovf);
                 push_prefix(pl->sgroup_prefix, ((u64)P.val_len + CH_G_STRINGS * CH_T - 1) / (CH_G_STRINGS * CH_T), ovf);
@@ -474,6 +490,16 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_vip = ap.take(pl->vidx_pages.size() * 4), o_plo = ap.take(n_pages * 8);
     const size_t o_sctp = ap.take(pl->stile_chain_prefix.size() * 4);
     const size_t o_str = ap.take(pl->stile_region.size() * 4);
+    {   // launch order of the units: the k-th unit of every chunk before the k+1-th of any, so that the units in flight
+        // are spread over all chunks and a unit's predecessors in its chunk are few and old
+        const size_t nu = pl->sunit_region.size();
+        pl->sunit_order.resize(nu);
+        std::vector<std::pair<u32, u32>> key(nu);
+        for (size_t u = 0; u < nu; u++) key[u] = {(u32)u - pl->sregions[pl->sunit_region[u]].lv_base, (u32)u};
+        std::sort(key.begin(), key.end());
+        for (size_t u = 0; u < nu; u++) pl->sunit_order[u] = key[u].second;
+    }
+    const size_t o_suo = ap.take(pl->sunit_order.size() * 4), o_sur = ap.take(pl->sunit_region.size() * 4);
     const size_t o_sgp = ap.take(pl->sgroup_prefix.size() * 4);
     const size_t o_ssp = ap.take(pl->ssuper_prefix.size() * 4);
     const size_t o_bp = ap.take(pl->bool_pages.size() * 4);
@@ -515,6 +541,9 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_status = ap.take(16);
     const size_t o_lvticket = ap.take(16);
     const size_t o_lvpos = ap.take((size_t)pl->n_lvtiles * 8), o_lvval = ap.take((size_t)pl->n_lvtiles * 8);  // hand-off granules
+    // strings, single pass: a status word per tile, a flag per chunk, one flag for the batch
+    const size_t o_sstat = ap.take(pl->sunit_region.size() * 8);
+    const size_t o_sfail = ap.take(pl->str_chunk_prefix.size() * 4), o_sany = ap.take(16);
     const size_t zero_end = ap.total;
     // the copy segment tables depend on output addresses → placed last, sized now
     size_t n_segs = 0;
@@ -618,6 +647,14 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                            n_sgroups, pl->d_sexit, pl->d_sgexit, pl->d_stile_entry, pl->d_sgroup_entry, pl->d_stotals, A + o_scp,
                            (u32*)(A + o_ssp), n_ssupers, (ExitRec*)(A + o_ssexit), (TileEntry*)(A + o_sse)};
     pl->schain.tile_region = (u32*)(A + o_str);
+    if (ctx->str_fused) {
+        pl->schain.str_stat = (u64*)(A + o_sstat);
+        pl->schain.str_failed = (u32*)(A + o_sfail);
+        pl->schain.str_any = (u32*)(A + o_sany);
+        pl->schain.n_units = (u32)pl->sunit_region.size();
+        pl->schain.unit_order = (u32*)(A + o_suo);
+        pl->schain.unit_region = (u32*)(A + o_sur);
+    }
     pl->schain.str_index = StrIndex{(const unsigned short*)(A + o_scand),
                                     (const unsigned short*)(A + o_sncand), (unsigned short*)(A + o_sgpre), (unsigned short*)(A + o_sspre)};
 
@@ -633,6 +670,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if ((rc = upload(ctx, pl->d_lvl_off, pl->page_lvl_off))) return rc;
     if ((rc = upload(ctx, pl->d_stile_chain_prefix, pl->stile_chain_prefix))) return rc;
     if ((rc = upload(ctx, (u32*)(A + o_str), pl->stile_region))) return rc;
+    if ((rc = upload(ctx, (u32*)(A + o_suo), pl->sunit_order))) return rc;
+    if ((rc = upload(ctx, (u32*)(A + o_sur), pl->sunit_region))) return rc;
     if ((rc = upload(ctx, pl->d_sgroup_prefix, pl->sgroup_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_ssuper_prefix, pl->ssuper_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_bool_pages, pl->bool_pages))) return rc;
@@ -686,9 +725,11 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     // first pass (k_str_page_scan), so nothing here waits for the levels; k_str_check compares with them at the end
     if (n_sreg) {
         if (str_early) HIP_TRY(ctx, hipStreamWaitEvent(sst, pl->ev_fork, 0));
+        // one pass over the page bytes; the two passes behind it only touch the chunks it gave up
+        if (pl->schain.str_stat) HIP_TRY(ctx, launch_str_fused(sst, src, pl->schain, pl->d_str_pd));
         HIP_TRY(ctx, launch_chain(sst, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_str_pd, pl->d_status, 0));
         HIP_TRY(ctx, launch_str_page_scan(sst, pl->d_sregions, pl->d_str_chunk_prefix, (u32)pl->str_chunk_prefix.size() - 1,
-                                          pl->d_stotals, pl->d_str_pd));
+                                          pl->d_stotals, pl->d_str_pd, pl->schain.str_failed));
     }
 
     // levels, then everything that only needs them
@@ -773,6 +814,9 @@ int pqd_plan_sync(pqd_plan* pl) {
         HIP_TRY(ctx, hipMemcpyAsync(pl->h_chunk_dyn.data(), pl->d_chunk_dyn, pl->h_chunk_dyn.size() * sizeof(ChunkDyn),
                                     hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(pl->h_status, pl->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+    pl->h_str_failed.assign(pl->schain.str_failed ? pl->str_chunk_prefix.size() - 1 : 0, 0);
+    if (!pl->h_str_failed.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(pl->h_str_failed.data(), pl->schain.str_failed, pl->h_str_failed.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     pl->synced = true;
     pl->last_status = map_status(pl->h_status[0]);
@@ -881,6 +925,13 @@ int pqd_plan_scatter(pqd_plan* pl, size_t c, void* dst_device, size_t dst_bytes)
     HIP_TRY(ctx, launch_scatter(ctx->stream, w, strings, C.validity, C.value_index, strings ? C.offsets : C.values, (u8*)dst_device,
                                 n_slots, (C.n_levels + 63) / 64, (u32)(src_cap < 0xFFFFFFFFull ? src_cap : 0xFFFFFFFFull)));
     return PQD_OK;
+}
+
+int64_t pqd_plan_string_fallbacks(pqd_plan* pl) {
+    if (!pl || !pl->synced) return PQD_E_ARG;
+    int64_t n = 0;
+    for (u32 f : pl->h_str_failed) n += f != 0;
+    return n;
 }
 
 int64_t pqd_plan_debug_stamps(pqd_plan* pl, void* dst, size_t cap) {

@@ -134,9 +134,26 @@ struct ChainArgs {
     TileEntry* super_entry;   // n_supers  (reset to 0xFF before every run)
     const u32* tile_region;   // n_tiles: the region of every tile (optional; null: the kernels search tile_prefix)
     StrIndex str_index;       // strings only (written by pass 1)
+    // strings, single pass (k_str_fused): null = the two passes decode every chunk
+    u64* str_stat;            // n_units status words {state, strings, exit}; zero before every run
+    u32 n_units;              // units of SF_TPU tiles of one page
+    const u32* unit_order;    // launch order: the k-th unit of every chunk before the k+1-th of any
+    const u32* unit_region;   // n_units
+    u32* str_failed;          // one word per BYTE_ARRAY chunk, zero before every run: set = the chunk goes through the two passes
+    u32* str_any;             // one word, zero before every run: set when any chunk was given up
 };
 hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs& a, RunRec* run_tbl, u32* otile_first_run,
                         const PageDyn* page_dyn, int* status, int phase);
+// strings in one pass over the page bytes; the chunks it gives up are flagged in a.str_failed and left to
+// launch_chain(KIND_STRINGS), whose kernels then skip every other chunk.  str_pd: one entry per string region.
+// Region fields on this path: count_level = first unit of the region, lv_base = first unit of the region's chunk,
+// run_base = bytes of the chunk's earlier pages (values regions), width = entries of the chunk's offsets array,
+// otile_base = index of the chunk among the BYTE_ARRAY chunks.
+constexpr u32 SF_WAVES = 16, SF_TPW = 2;       // waves per workgroup (unit), tiles per wave
+constexpr u32 SF_TPU = SF_WAVES * SF_TPW;      // tiles per unit
+constexpr u32 SF_REP_MAX = 2;                  // tiles of a unit that may be walked string by string
+static_assert(SF_TPU <= 64, "one lane per tile of a unit");
+hipError_t launch_str_fused(hipStream_t st, const u8* src, const ChainArgs& a, PageDyn* str_pd);
 // otile_region: region of every expand tile plus one spare entry (may be null: the kernel then searches
 // otile_prefix); otile_first_run must have one spare entry after its n_otiles.
 hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_region,
@@ -200,7 +217,7 @@ hipError_t launch_scatter(hipStream_t st, int width, bool offsets, const u8* val
 // strings: per-page value and char offsets within the chunk from the first pass's string counts (one wave per
 // string chunk; region_prefix has n_str_chunks + 1 entries); str_pd is indexed by string region
 hipError_t launch_str_page_scan(hipStream_t st, const Region* regions, const u32* region_prefix, u32 n_str_chunks,
-                                const RegionTotal* totals, PageDyn* str_pd);
+                                const RegionTotal* totals, PageDyn* str_pd, const u32* gate);
 hipError_t launch_str_check(hipStream_t st, const PageRec* pages, const ChunkRec* chunks, const PageDyn* page_dyn,
                             const Region* regions, u32 n_regions, const RegionTotal* totals, int* status);
 hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_prefix, const u32* rtile_owner, const u32* chunk_ids,

@@ -587,8 +587,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
                                                           const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
                                                           ExitRec* __restrict__ exit_tbl, u32x4* __restrict__ str_cp,
                                                           const u32* __restrict__ tile_region,
-                                                          unsigned short* __restrict__ str_cand, unsigned short* __restrict__ str_ncand) {
+                                                          unsigned short* __restrict__ str_cand, unsigned short* __restrict__ str_ncand,
+                                                          const u32* __restrict__ gate, const u32* __restrict__ gate_any) {
     static_assert(STR_CP == 8, "a checkpoint row is 8 x u16");
+    if (gate_any && !*gate_any) return;  // behind the single pass: only the chunks it gave up are decoded here
     constexpr u32 E = CH_E_STRINGS, A = STR_A;
     __shared__ __attribute__((aligned(16))) u32 s_tile[A * STR_LDS_WORDS];
     __shared__ u32 s_tb[A], s_len[A], s_found[A];
@@ -605,16 +607,17 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
     __shared__ u64 s_msrc[STR_ITER * A];
     static_assert(STR_ITER * A <= CH_THREADS, "one lane per tile of the workgroup for the region lookups");
     const u32 lane = threadIdx.x, tile_first = blockIdx.x * STR_ITER * A;
-    if (lane < STR_ITER * A) {
+    {
         u32 tb = 0, len = 0;
         u64 so = 0;
         const u32 tile = tile_first + lane;
-        if (tile < n_tiles) {
+        if (lane < STR_ITER * A && tile < n_tiles) {
             const u32 ri = tile_region ? tile_region[tile] : find_owner(tile_prefix, n_regions, tile);
             const Region R = regions[ri];
-            tb = (tile - tile_prefix[ri]) * CH_T; len = R.len; so = R.src_off;
+            if (!gate || gate[R.otile_base]) { tb = (tile - tile_prefix[ri]) * CH_T; len = R.len; so = R.src_off; }
         }
-        s_mtb[lane] = tb; s_mlen[lane] = len; s_msrc[lane] = so;  // absent tiles: length 0, nothing is plausible
+        if (gate && !__ballot(len != 0)) return;  // one wave per workgroup: no tile of a chunk that was given up
+        if (lane < STR_ITER * A) { s_mtb[lane] = tb; s_mlen[lane] = len; s_msrc[lane] = so; }  // absent tiles: length 0, nothing is plausible
     }
     __syncthreads();
     // every tile of group `it` complete, lookahead included: its loads can all be in flight at once
@@ -896,7 +899,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
                                                          const TileEntry* __restrict__ tile_entry,
                                                          const u32x4* __restrict__ str_cp,
                                                          const PageDyn* __restrict__ page_dyn, const u32* __restrict__ tile_region,
-                                                         const int* __restrict__ status) {
+                                                         const int* __restrict__ status, const u32* __restrict__ gate_any) {
+    if (gate_any && !*gate_any) return;  // behind the single pass: only tiles of the chunks it gave up have entries
     if (status && status[0]) return;  // an earlier kernel found the batch corrupt: value counts and offsets are not to be trusted
     __shared__ __attribute__((aligned(16))) u32 s_buf[STR_MG][STR_LDS_WORDS];
     __shared__ u32 s_bits[STR_MG][64], s_last[STR_MG][2];
@@ -1068,6 +1072,406 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
     }
 }
 
+// =====================================================================================
+// k_str_fused — the strings of a page batch in ONE pass over the page bytes (template_string.go:47-58,
+// template_string_optional.go:68-79).  The two passes above read every page twice because a tile cannot know where
+// the chain of length prefixes enters it.  Here every tile GUESSES its string starts from its own bytes, proves the
+// guess against itself and against its neighbour, and writes offsets and chars at once; a chunk in which a proof fails
+// is handed, on the device, to the exact two-pass kernels, which run behind this one and skip every other chunk.
+//   guess      a position is a candidate when its four bytes are a plausible length (str_cand_room).  Every true start
+//              is one.  In text the only others are the one or two positions in front of a true start (their length
+//              has the true length in a higher byte), so the guess is: a candidate whose successor position is not a
+//              candidate.
+//   proof      inside the tile: every guessed start's end (start + 4 + length) is the next guessed start, and the last
+//              one's end lies at or beyond the tile's end (its exit).  Between tiles: the exit of the tile before is this
+//              tile's first guessed start; a page's first tile starts at 0.  By induction over the tiles of a page the
+//              guessed starts are then exactly the chain the reference walks.  A tile without any candidate is passed
+//              over by a string from before (its exit is its predecessor's).
+//   ranks      the number of strings in front of a tile within its column chunk is a sum over the tiles before it: a
+//              decoupled look-back over one 64-bit status word per tile {state, strings, exit}.  A tile publishes its
+//              own count (AGG) as soon as its guess has proved itself, looks back over the words of the tiles before it
+//              (64 at a time, one per lane) down to the first inclusive prefix, and publishes its inclusive prefix.
+//              Chars and offsets of the whole chunk follow from the rank alone: string number g that starts at stream
+//              position q has its chars at q - 4 g.
+//   repair     a tile whose guess does not prove itself has published nothing: it waits for the exit of the tile
+//              before it and walks its strings one by one from there (one lane; ~10 us, during which the tiles behind
+//              it wait).  Not more than SF_REP_MAX tiles in a row may do so; then, and whenever a published guess
+//              turns out wrong, a walk meets a bad length, or a wait runs out, the chunk is given up.
+// Workgroups wait only for workgroups with lower block indices, which the dispatcher starts first; a wait that
+// still runs out (SF_TIMEOUT) gives the chunk up instead of hanging.
+// Nothing here reports corrupt data: a chunk that is given up gets its verdict from the two-pass kernels.
+// =====================================================================================
+constexpr u64 SF_AGG = 1, SF_INCL = 2, SF_FAIL = 3;  // state of a unit's status word (0: nothing published yet)
+constexpr u32 SF_PASS = 0xFFFFFFFDu;       // exit of a tile (unit) in which no string starts: the exit of the one before it
+constexpr u32 SF_CNT_MAX = (1u << 28) - 1; // strings of a chunk that the status word can count
+constexpr u64 SF_TIMEOUT = 2000000;        // wall-clock ticks (100 MHz) a unit waits for the units before it: 20 ms
+constexpr u32 SF_THREADS = SF_WAVES * 64;
+static __device__ __forceinline__ u64 sf_pack(u64 state, u32 cnt, u32 exit) { return state << 62 | (u64)cnt << 32 | exit; }
+static __device__ __forceinline__ u64 sf_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ void sf_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ u32 sf_wave_sum(u32 v) {
+#pragma unroll
+    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// What the units in front of unit `ui` say (one wave): strings in front of it within its chunk (units cf..ui-1) and the
+// exit of the nearest unit in front of it in its page that has one (0 for a page's first unit, rf).  False: the chunk
+// was given up (by another unit, or here because the wait ran out).
+static __device__ __forceinline__ bool sf_lookback(const u64* __restrict__ ustat, u32 ui, u32 cf, u32 rf, const u32* chunk_failed,
+                                                   u32 lane, u32& excl, u32& pexit) {
+    excl = 0;
+    bool have_exit = ui == rf;
+    pexit = 0;
+    bool counted = false;
+    long long base = ui;
+    u64 t_start = 0;
+    while (true) {
+        const long long j = base - 1 - (long long)lane;
+        const bool valid = j >= (long long)cf;
+        const u64 wd = valid ? sf_load(ustat + j) : sf_pack(SF_INCL, 0, 0);  // in front of the chunk: an empty prefix
+        const u32 st = (u32)(wd >> 62);
+        const u64 m_incl = __ballot(st == SF_INCL), m_nr = __ballot(st == 0);
+        if (__ballot(st == SF_FAIL)) return false;
+        const u32 fi = m_incl ? (u32)__ffsll((unsigned long long)m_incl) - 1 : 64;
+        const u64 need = fi >= 63 ? ~0ull : (2ull << fi) - 1;  // lanes 0..fi
+        if (m_nr & need) {
+            if (__hip_atomic_load(chunk_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            const u64 now = wall_clock64();
+            if (!t_start) t_start = now;
+            else if (now - t_start > SF_TIMEOUT) return false;
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        if (!counted) excl += sf_wave_sum(lane <= fi ? (u32)(wd >> 32) & SF_CNT_MAX : 0);
+        if (!have_exit) {
+            const u64 mc = __ballot(lane <= fi && j >= (long long)rf && (u32)wd != SF_PASS);
+            if (mc) {
+                pexit = (u32)__shfl(wd, (int)__ffsll((unsigned long long)mc) - 1);
+                have_exit = true;
+            }
+        }
+        if (fi < 64) counted = true;
+        if (counted && have_exit) return true;
+        base -= 64;
+        if (base <= (long long)cf && !have_exit) return false;  // cannot happen: a page's first unit has an exit
+    }
+}
+
+__global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                                                          const u32* __restrict__ unit_order, const u32* __restrict__ unit_region,
+                                                          u64* __restrict__ ustat, u32* __restrict__ chunk_failed,
+                                                          u32* __restrict__ any_failed) {
+    constexpr u32 NT = SF_TPW;
+    __shared__ __attribute__((aligned(16))) u32 s_buf[SF_TPU][STR_LDS_WORDS];
+    __shared__ u32 s_cnt[SF_TPU], s_ent[SF_TPU], s_ext[SF_TPU], s_lastq[SF_TPU], s_excl[SF_TPU], s_epos[SF_TPU], s_slot[SF_TPU];
+    __shared__ u32 s_bits[SF_REP_MAX][64];
+    __shared__ u32 s_alive;
+    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u32 ui = unit_order[blockIdx.x];
+    const Region R = regions[unit_region[ui]];
+    const u32 L = R.len;
+    const u32 k0 = (ui - R.count_level) * SF_TPU;      // the unit's first tile within its page
+    const u32 n_on = (L - k0 * CH_T + CH_T - 1) / CH_T < SF_TPU ? (L - k0 * CH_T + CH_T - 1) / CH_T : SF_TPU;  // its tiles (>= 1)
+    const u8* const rsrc = src_base + R.src_off;
+    bool on[NT];
+    u32 tb[NT], lim[NT], rlim[NT];
+    u32 w[NT][8];
+#pragma unroll
+    for (u32 t = 0; t < NT; t++) {
+        const u32 tu = wv * NT + t;
+        on[t] = tu < n_on;
+        tb[t] = (k0 + tu) * CH_T;
+        lim[t] = tb[t] + CH_T < L ? tb[t] + CH_T : L;
+        rlim[t] = on[t] ? lim[t] - tb[t] : 0;
+        if (on[t]) str_stage_tile(rsrc, L, tb[t], lane, w[t], s_buf[tu]);
+    }
+    __builtin_amdgcn_wave_barrier();  // a wave reads only the tile images it wrote itself until the first barrier
+
+    // ---- guess and proof inside each tile
+    u32 S[NT], cnt[NT], ext[NT], lastq[NT];
+    bool ok[NT];
+#pragma unroll
+    for (u32 t = 0; t < NT; t++) {
+        const u32 tu = wv * NT + t;
+        S[t] = 0; cnt[t] = 0; ext[t] = SF_PASS; lastq[t] = ERR_POS; ok[t] = true;
+        if (!on[t]) continue;
+        const u32* const tl = s_buf[tu];
+        const u32 la = tl[CH_T / 4];  // the four bytes behind the tile
+        u32 nw = __shfl_down(w[t][0], 1);
+        if (lane == 63) nw = la;
+        const u32 W9[9] = {w[t][0], w[t][1], w[t][2], w[t][3], w[t][4], w[t][5], w[t][6], w[t][7], nw};
+        u32 C = 0;
+        if ((u64)tb[t] + CH_T + 4 + STR_CAND_MAX <= L) {  // every position of the tile has STR_CAND_MAX bytes of page behind it
+#pragma unroll
+            for (int k = 31; k >= 0; k--) {
+                const u32 x = (k & 3) ? __builtin_amdgcn_alignbit(W9[k / 4 + 1], W9[k / 4], (k & 3) * 8) : W9[k / 4];
+                C = (C << 1) | (u32)(x < STR_CAND_MAX);
+            }
+        } else {
+            const int room0 = (int)L - 3 - (int)(tb[t] + lane * CH_SUB);
+#pragma unroll
+            for (int k = 31; k >= 0; k--) {
+                const u32 x = (k & 3) ? __builtin_amdgcn_alignbit(W9[k / 4 + 1], W9[k / 4], (k & 3) * 8) : W9[k / 4];
+                C = (C << 1) | (u32)(x < str_cand_room(room0 - k));
+            }
+        }
+        u32 c_next = __shfl_down(C, 1) & 1;
+        if (lane == 63) c_next = la < str_cand_room((int)L - 3 - (int)(tb[t] + CH_T));
+        const u32 Sm = C & ~((C >> 1) | (c_next << 31));
+        // the first guessed start in the lanes above mine, and of the tile
+        u32 v = Sm ? lane * CH_SUB + (u32)__ffs(Sm) - 1 : 0xFFFFu;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 y = __shfl_down(v, d);
+            if (lane + d < 64) v = y < v ? y : v;
+        }
+        u32 nf = __shfl_down(v, 1);
+        if (lane == 63) nf = 0xFFFFu;
+        const u32 ent = __shfl(v, 0);
+        bool good = true;
+        u32 my_exit = 0, my_last = 0xFFFFu, m = Sm;
+        while (__any(m != 0)) {
+            if (m) {
+                const u32 k = (u32)__ffs(m) - 1;
+                m &= m - 1;
+                const u32 p = lane * CH_SUB + k;
+                const u32 nx = p + 4 + str_len_at(tl, p);  // a candidate's length fits in the page
+                const u32 succ = m ? lane * CH_SUB + (u32)__ffs(m) - 1 : nf;
+                if (succ == 0xFFFFu) { good = good && nx >= rlim[t]; my_exit = nx; my_last = p; }
+                else good = good && nx == succ;
+            }
+        }
+        ok[t] = __all(good);
+        S[t] = Sm;
+        cnt[t] = sf_wave_sum(__popc(Sm));
+        const u64 bl = __ballot(my_last != 0xFFFFu);  // the lane of the tile's last start, if it has one
+        if (bl) {
+            const int l = __ffsll((unsigned long long)bl) - 1;
+            ext[t] = tb[t] + __shfl(my_exit, l);
+            lastq[t] = tb[t] + __shfl(my_last, l);
+        }
+        if (lane == 0) {
+            s_cnt[tu] = ok[t] ? cnt[t] : 0xFFFFFFFFu;  // 0xFFFFFFFF: the guess did not prove itself
+            s_ent[tu] = tb[t] + ent;
+            s_ext[tu] = ext[t];
+            s_lastq[tu] = lastq[t];
+        }
+    }
+    __syncthreads();
+
+    // ---- the unit: ranks, the proof between tiles, repairs (wave 0)
+    if (wv == 0) {
+        const bool mine = lane < n_on;
+        u32 c = mine ? s_cnt[lane] : 0, e = mine ? s_ext[lane] : SF_PASS;
+        const u32 en = mine ? s_ent[lane] : 0;
+        const u32 t_lim = (k0 + lane + 1) * CH_T < L ? (k0 + lane + 1) * CH_T : L;
+        const bool all_ok = !__ballot(c == 0xFFFFFFFFu);
+        const u32 cf = R.lv_base, rf = R.count_level;
+        u32* const cfail = chunk_failed + R.otile_base;
+        // the last tile with an exit of its own, if any
+        const u64 m_ex = __ballot(mine && e != SF_PASS);
+        u32 tot = 0, uexit = SF_PASS;
+        if (all_ok) {
+            tot = sf_wave_sum(c);
+            if (m_ex) uexit = __shfl(e, 63 - (int)__clzll((unsigned long long)m_ex));
+            if (lane == 0) sf_store(ustat + ui, sf_pack(SF_AGG, tot, uexit));
+        }
+        u32 uexcl = 0, pexit = 0;
+        bool alive = sf_lookback(ustat, ui, cf, rf, cfail, lane, uexcl, pexit);
+        u32 epos = ERR_POS, slot = 0xFFFFFFFFu;
+        if (alive && all_ok) {
+            // the exit of the nearest tile in front of mine that has one (else the unit's predecessor's)
+            const u64 below = m_ex & ((1ull << lane) - 1);
+            const u32 e_below = __shfl(e, below ? 63 - (int)__clzll((unsigned long long)below) : 0);  // every lane takes part: a lane outside a shuffle is read as 0
+            const u32 pe = below ? e_below : pexit;
+            const bool bad = mine && (c ? en != pe : pe < t_lim);
+            if (__ballot(bad)) alive = false;
+            if (c) epos = pe;
+            if (uexit == SF_PASS) uexit = pexit;
+        } else if (alive) {
+            // some guess failed: one lane goes through the tiles in order and walks the failed ones string by string
+            if (lane == 0) {
+                u32 pe = pexit, nrep = 0;
+                for (u32 t = 0; t < n_on && alive; t++) {
+                    const u32 tbt = (k0 + t) * CH_T, limt = tbt + CH_T < L ? tbt + CH_T : L;
+                    const u32 ct = s_cnt[t];
+                    s_slot[t] = 0xFFFFFFFFu;
+                    if (ct != 0xFFFFFFFFu) {
+                        if (ct ? s_ent[t] != pe : pe < limt) { alive = false; break; }
+                        s_epos[t] = ct ? pe : ERR_POS;
+                        if (ct) pe = s_ext[t];
+                        continue;
+                    }
+                    if (nrep == SF_REP_MAX) { alive = false; break; }
+                    u32 n = 0, lastq = ERR_POS;
+                    if (pe < limt) {
+                        u32* const bits = s_bits[nrep];
+                        for (u32 i = 0; i < 64; i++) bits[i] = 0;
+                        const u32* const tl = s_buf[t];
+                        const u32 avail = L - tbt, room0 = avail - 3, rend = limt - tbt;
+                        const u32 rend4 = avail < 4 ? 0 : rend < room0 ? rend : room0;
+                        u32 rel = pe - tbt, last_rel = rel;
+                        while (rel < rend4) {
+                            bits[rel >> 5] |= 1u << (rel & 31);
+                            const u32 len = str_len_at(tl, rel);
+                            last_rel = rel;
+                            rel = len < room0 - rel ? rel + 4 + len : ERR_POS;
+                            n++;
+                        }
+                        if (rel < rend) rel = ERR_POS;  // a start in the last three bytes of the page
+                        if (rel == ERR_POS) { alive = false; break; }  // a bad length: the two passes report it
+                        s_slot[t] = nrep++;
+                        s_epos[t] = pe;
+                        lastq = tbt + last_rel;
+                        pe = tbt + rel;
+                        s_ext[t] = pe;
+                    } else s_epos[t] = ERR_POS;
+                    s_cnt[t] = n;
+                    s_lastq[t] = lastq;
+                }
+                uexit = pe;
+            }
+            alive = __shfl((u32)alive, 0) != 0;
+            uexit = __shfl(uexit, 0);
+            if (alive) {
+                c = mine ? s_cnt[lane] : 0;
+                epos = mine ? s_epos[lane] : ERR_POS;
+                slot = mine ? s_slot[lane] : 0xFFFFFFFFu;
+                tot = sf_wave_sum(c);
+            }
+        }
+        if (alive && (u64)uexcl + tot > SF_CNT_MAX) alive = false;
+        if (alive) {
+            u32 incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const u32 y = __shfl_up(incl, d);
+                if (lane >= (u32)d) incl += y;
+            }
+            if (mine) { s_excl[lane] = uexcl + incl - c; s_epos[lane] = epos; s_cnt[lane] = c; s_slot[lane] = slot; }
+            if (lane == 0) sf_store(ustat + ui, sf_pack(SF_INCL, uexcl + tot, uexit));
+        } else if (lane == 0) {
+            __hip_atomic_store(cfail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(any_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sf_store(ustat + ui, sf_pack(SF_FAIL, 0, 0));
+        }
+        if (lane == 0) s_alive = alive;
+    }
+    __syncthreads();
+    if (!s_alive) return;
+
+    // ---- offsets and chars (as in k_str_mark): string number g starting at stream position q has its chars at q - 4 g
+    u32 n_chars[NT], pad[NT], excl[NT], epos[NT];
+    u8* cdst[NT];
+    bool emit[NT];
+#pragma unroll
+    for (u32 t = 0; t < NT; t++) {
+        const u32 tu = wv * NT + t;
+        n_chars[t] = 0; pad[t] = 0; cdst[t] = nullptr; excl[t] = 0; epos[t] = ERR_POS;
+        emit[t] = on[t] && s_cnt[tu] > 0;
+        if (!emit[t]) continue;
+        excl[t] = s_excl[tu]; epos[t] = s_epos[tu];
+        if (s_slot[tu] != 0xFFFFFFFFu) {  // walked string by string
+            S[t] = s_bits[s_slot[tu]][lane];
+            ext[t] = s_ext[tu]; lastq[t] = s_lastq[tu];
+        }
+        const u64 q0 = R.run_base + epos[t];  // stream position of the tile's first start
+        if (q0 < 4ull * excl[t]) {  // only a rank from a wrong guess elsewhere can do this: the chunk is being given up
+            emit[t] = false;
+            if (lane == 0) {
+                __hip_atomic_store(chunk_failed + R.otile_base, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(any_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            continue;
+        }
+        const u32 sub_lo = tb[t] + lane * CH_SUB, sub_hi = sub_lo + CH_SUB;
+        const u32 smask = S[t];
+        u32 prev = __shfl_up(smask, 1);
+        if (lane == 0) prev = 0;
+        const u32 lenmask = smask | (smask << 1) | (smask << 2) | (smask << 3) | ((prev >> 29) & 1) | (((prev >> 30) & 1) * 3) |
+                            (((prev >> 31) & 1) * 7);
+        const u32 k_lo = epos[t] <= sub_lo ? 0 : epos[t] >= sub_hi ? 32 : epos[t] - sub_lo;
+        const u32 k_hi = lim[t] >= sub_hi ? 32 : lim[t] <= sub_lo ? 0 : lim[t] - sub_lo;
+        u32 own = k_lo >= 32 ? 0 : 0xFFFFFFFFu << k_lo;
+        if (k_hi < 32) own &= (1u << k_hi) - 1;
+        const u32 charmask = own & ~lenmask;
+        const u32 mine = __popc(charmask) | (__popc(smask) << 16);
+        u32 incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 x = __shfl_up(incl, d);
+            if (lane >= (u32)d) incl += x;
+        }
+        n_chars[t] = __shfl(incl, 63) & 0xFFFF;
+        const u32 pc = (incl - mine) & 0xFFFF, ps = (incl - mine) >> 16;
+        {
+            int32_t* const offs = (int32_t*)R.out;
+            const u32 cap = R.width;  // entries of the chunk's offsets array in front of the closing one
+            const u32 sbase = (u32)R.run_base + sub_lo;
+            u32 m = smask, rank = excl[t] + ps;
+            while (m) {
+                const u32 k = __ffs(m) - 1;
+                m &= m - 1;
+                if (rank < cap) offs[rank] = (int32_t)(sbase + k - 4u * rank);
+                rank++;
+            }
+        }
+        cdst[t] = R.out2 + (q0 - 4ull * excl[t]);
+        pad[t] = (u32)((uintptr_t)cdst[t] & 15);
+        u8* const stage = (u8*)s_buf[tu];  // every read of the tile image is over
+#pragma unroll
+        for (int k = 0; k < (int)CH_SUB; k++)
+            if ((charmask >> k) & 1) stage[pad[t] + pc + __popc(charmask & ((1u << k) - 1))] = (u8)(w[t][k >> 2] >> (8 * (k & 3)));
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (u32 t = 0; t < NT; t++) {
+        if (!emit[t]) continue;
+        const u32 tu = wv * NT + t;
+        const u8* const stage = (const u8*)s_buf[tu];
+        u8* const cd = cdst[t];
+        const u32 pd0 = pad[t], n_stg = pd0 + n_chars[t];
+        const u32 head_end = ((pd0 + 15) & ~15u) < n_stg ? ((pd0 + 15) & ~15u) : n_stg;
+        const u32 tail_lo = (n_stg & ~15u) > head_end ? (n_stg & ~15u) : head_end;
+        for (u32 c0 = head_end + lane * 16; c0 < tail_lo; c0 += 64 * 16) *(u32x4*)(cd - pd0 + c0) = *(const u32x4*)(stage + c0);
+        if (lane < 16) { if (pd0 + lane < head_end) cd[lane] = stage[pd0 + lane]; }
+        else if (lane < 32) { const u32 b = tail_lo + lane - 16; if (b < n_stg) cd[b - pd0] = stage[b]; }
+        // the last string of the tile may run past the tile: its remaining chars follow directly
+        const u32 lq = lastq[t], ln = ext[t];
+        if (ln != ERR_POS && ln != SF_PASS && ln > lim[t]) {
+            const u32 s_lo = lq + 4 > lim[t] ? lq + 4 : lim[t];
+            const u8* sp = rsrc + s_lo;
+            u8* dp = cd + n_chars[t];
+            const u32 n = ln - s_lo, n16 = n & ~15u;
+            for (u32 c0 = lane * 16; c0 < n16; c0 += 64 * 16) *(u32x4_u*)(dp + c0) = *(const u32x4_u*)(sp + c0);
+            if (lane < 16 && n16 + lane < n) dp[n16 + lane] = sp[n16 + lane];
+        }
+    }
+}
+
+// k_str_totals — after k_str_fused, one thread per string page: the page's string count and its place in the chunk's
+// arrays, from the inclusive prefixes of the tiles at the page's borders (what k_chain_resolve and k_str_page_scan
+// leave on the two-pass path, which writes them itself for the chunks that were given up).
+__global__ void k_str_totals(const Region* __restrict__ regions, u32 n_regions,
+                             const u64* __restrict__ ustat, const u32* __restrict__ chunk_failed,
+                             RegionTotal* __restrict__ totals, PageDyn* __restrict__ str_pd) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_regions) return;
+    const Region R = regions[r];
+    if (chunk_failed[R.otile_base]) return;
+    // units of the page: [lo, hi); units of one chunk are numbered in page order from cf
+    const u32 lo = R.count_level, hi = lo + (R.len + SF_TPU * CH_T - 1) / (SF_TPU * CH_T), cf = R.lv_base;
+    const u32 before = lo > cf ? (u32)(ustat[lo - 1] >> 32) & SF_CNT_MAX : 0;
+    const u32 upto = hi > cf ? (u32)(ustat[hi - 1] >> 32) & SF_CNT_MAX : 0;
+    RegionTotal T;
+    T.cnt = upto - before; T.err = 0; T.vals = 0;
+    totals[r] = T;
+    PageDyn D;
+    D.nn = T.cnt; D.pad = 0; D.val_off = before; D.char_off = R.run_base - 4ull * before;
+    str_pd[r] = D;
+}
+
 // ---- hopping from tile to tile along the true chain, in three levels so that no thread makes more
 // than a few dozen dependent loads:
 //   k_chain_groups    per group of G tiles and per tabulated entry of its first tile: where the chain
@@ -1204,10 +1608,11 @@ template <int KIND>
 __global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                      const u32* __restrict__ group_prefix, u32 n_regions, u32 n_groups,
                                                      const ExitRec* __restrict__ exit_tbl, ExitRec* __restrict__ gexit,
-                                                     const StrIndex sx) {
+                                                     const StrIndex sx, const u32* __restrict__ gate, const u32* __restrict__ gate_any) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     constexpr u32 G = chain_group_tiles(KIND);
     static_assert(E % 64 == 0 || 64 % E == 0, "whole waves per group or whole groups per wave");
+    if (gate_any && !*gate_any) return;
     // one lane per (group, row): E / 64 waves per group, or 64 / E groups per wave when a table has fewer rows than a wave has lanes
     constexpr u32 LPG = E < 64 ? E : 64;  // lanes of a wave that work on the same group
     const u32 gid = blockIdx.x * 64 + threadIdx.x;
@@ -1216,6 +1621,7 @@ __global__ __launch_bounds__(64) void k_chain_groups(const u8* __restrict__ src_
     if (group >= n_groups) return;
     const u32 ri = find_owner(group_prefix, n_regions, group);
     const Region R = regions[ri];
+    if (gate && !gate[R.otile_base]) return;
     const u32 L = R.len;
     const u32 g_lo = (group - group_prefix[ri]) * G * CH_T;
     const u32 g_hi = g_lo + G * CH_T < L ? g_lo + G * CH_T : L;
@@ -1256,15 +1662,17 @@ template <int KIND>
 __global__ __launch_bounds__(64) void k_chain_supers(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                      const u32* __restrict__ super_prefix, u32 n_regions,
                                                      const ExitRec* __restrict__ gexit, ExitRec* __restrict__ sexit,
-                                                     const StrIndex sx) {
+                                                     const StrIndex sx, const u32* __restrict__ gate, const u32* __restrict__ gate_any) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     constexpr u32 G = chain_group_tiles(KIND);
     constexpr u32 GB = G * CH_T;  // bytes per group
     constexpr u32 BPG = E > 64 ? E / 64 : 1;
+    if (gate_any && !*gate_any) return;
     const u32 sup = blockIdx.x / BPG;
     const u32 i = (blockIdx.x % BPG) * 64 + threadIdx.x;
     const u32 ri = find_owner(super_prefix, n_regions, sup);
     const Region R = regions[ri];
+    if (gate && !gate[R.otile_base]) return;
     const u32 L = R.len;
     const u64 s_lo64 = (u64)(sup - super_prefix[ri]) * CH_SUPER * GB;
     const u32 s_lo = (u32)s_lo64;
@@ -1317,12 +1725,13 @@ __global__ void k_chain_resolve(const u8* __restrict__ src_base, const Region* _
                                 const u32* __restrict__ super_prefix, const ExitRec* __restrict__ sexit,
                                 TileEntry* __restrict__ super_entry,
                                 TileEntry* __restrict__ group_entry, RegionTotal* __restrict__ totals,
-                                int* __restrict__ status, const StrIndex sx) {
+                                int* __restrict__ status, const StrIndex sx, const u32* __restrict__ gate) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     constexpr u32 G = chain_group_tiles(KIND);
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_regions) return;
     const Region R = regions[r];
+    if (gate && !gate[R.otile_base]) return;
     const u32 L = R.len;
     const GlobalBytes B{src_base + R.src_off};
     u32 p = 0, cnt = 0;
@@ -1370,8 +1779,9 @@ __global__ void k_chain_super_groups(const u8* __restrict__ src_base, const Regi
                                      const u32* __restrict__ super_prefix, u32 n_regions, u32 n_supers,
                                      const ExitRec* __restrict__ exit_tbl, const ExitRec* __restrict__ gexit,
                                      const TileEntry* __restrict__ super_entry, TileEntry* __restrict__ group_entry,
-                                     const StrIndex sx) {
+                                     const StrIndex sx, const u32* __restrict__ gate_any) {
     constexpr u32 G = chain_group_tiles(KIND);
+    if (gate_any && !*gate_any) return;
     const u32 sup = blockIdx.x * blockDim.x + threadIdx.x;
     if (sup >= n_supers) return;
     const TileEntry se = super_entry[sup];
@@ -1397,8 +1807,9 @@ template <int KIND>
 __global__ void k_chain_tiles(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                               const u32* __restrict__ group_prefix, u32 n_regions, u32 n_groups,
                               const ExitRec* __restrict__ exit_tbl, const TileEntry* __restrict__ group_entry,
-                              TileEntry* __restrict__ tile_entry, const StrIndex sx) {
+                              TileEntry* __restrict__ tile_entry, const StrIndex sx, const u32* __restrict__ gate_any) {
     constexpr u32 G = chain_group_tiles(KIND);
+    if (gate_any && !*gate_any) return;
     const u32 group = blockIdx.x * blockDim.x + threadIdx.x;
     if (group >= n_groups) return;
     const TileEntry ge = group_entry[group];
@@ -1784,9 +2195,10 @@ __global__ __launch_bounds__(256) void k_bools(const u8* __restrict__ src_base, 
 // therefore needs nothing from the levels.  region_prefix[k] = first string region (page) of the k-th string chunk.
 __global__ __launch_bounds__(64) void k_str_page_scan(const Region* __restrict__ regions, const u32* __restrict__ region_prefix,
                                                       u32 n_str_chunks, const RegionTotal* __restrict__ totals,
-                                                      PageDyn* __restrict__ str_pd) {
+                                                      PageDyn* __restrict__ str_pd, const u32* __restrict__ gate) {
     const u32 c = blockIdx.x;
     if (c >= n_str_chunks) return;
+    if (gate && !gate[c]) return;  // decoded by the single pass, which left this chunk's entries itself
     const u32 r0 = region_prefix[c], r1 = region_prefix[c + 1], lane = threadIdx.x;
     u64 run_vals = 0, run_chars = 0;
     for (u32 base = r0; base < r1; base += 64) {
@@ -2281,48 +2693,51 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
                                  const PageDyn* page_dyn, int* status, int phase) {
     constexpr u32 E = KIND == KIND_STRINGS ? CH_E_STRINGS : CH_E_LEVELS;
     if (a.n_regions == 0) return hipSuccess;
+    // strings behind the single pass: only the chunks it gave up
+    const u32* const gate = KIND == KIND_STRINGS ? a.str_failed : nullptr;
+    const u32* const gate_any = KIND == KIND_STRINGS ? a.str_any : nullptr;
     if (phase == 0) {
         if (a.n_tiles) {
             if constexpr (KIND == KIND_STRINGS)
                 hipLaunchKernelGGL(k_str_exits, dim3((a.n_tiles + STR_A * STR_ITER - 1) / (STR_A * STR_ITER)), dim3(CH_THREADS), 0, st, src, a.regions,
                                    a.tile_prefix, a.n_regions, a.n_tiles, a.exit_tbl, (u32x4*)a.str_cp, a.tile_region,
                                    (unsigned short*)a.str_index.cand,
-                                   (unsigned short*)a.str_index.ncand);
+                                   (unsigned short*)a.str_index.ncand, gate, gate_any);
             else
                 hipLaunchKernelGGL((k_chain<KIND, false, CHAIN_NT>), dim3(a.n_tiles), dim3(CHAIN_NT), 0, st, src, a.regions,
                                    a.tile_prefix, a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn,
                                    a.tile_region);
             LAUNCH_CHECK();
             hipLaunchKernelGGL((k_chain_groups<KIND>), dim3((u32)(((u64)a.n_groups * E + 63) / 64)), dim3(64), 0, st, src, a.regions,
-                               a.group_prefix, a.n_regions, a.n_groups, a.exit_tbl, a.gexit, a.str_index);
+                               a.group_prefix, a.n_regions, a.n_groups, a.exit_tbl, a.gexit, a.str_index, gate, gate_any);
             LAUNCH_CHECK();
         }
         const bool supers = a.n_supers > 0;
         if (supers) {
             hipLaunchKernelGGL((k_chain_supers<KIND>), dim3(a.n_supers * (E > 64 ? E / 64 : 1)), dim3(64), 0, st, src, a.regions,
-                               a.super_prefix, a.n_regions, a.gexit, a.sexit, a.str_index);
+                               a.super_prefix, a.n_regions, a.gexit, a.sexit, a.str_index, gate, gate_any);
             LAUNCH_CHECK();
         }
         // the region hop also runs for empty regions: it writes their (zero) totals
         hipLaunchKernelGGL((k_chain_resolve<KIND>), dim3((a.n_regions + 63) / 64), dim3(64), 0, st, src, a.regions, a.n_regions,
                            a.exit_tbl, a.gexit, a.super_prefix, supers ? a.sexit : nullptr, a.super_entry, a.group_entry,
-                           a.totals, status, a.str_index);
+                           a.totals, status, a.str_index, gate);
         LAUNCH_CHECK();
         if (supers) {
             hipLaunchKernelGGL((k_chain_super_groups<KIND>), dim3((a.n_supers + 63) / 64), dim3(64), 0, st, src, a.regions,
                                a.super_prefix, a.n_regions, a.n_supers, a.exit_tbl, a.gexit, a.super_entry, a.group_entry,
-                               a.str_index);
+                               a.str_index, gate_any);
             LAUNCH_CHECK();
         }
         if (a.n_tiles) {
             hipLaunchKernelGGL((k_chain_tiles<KIND>), dim3((a.n_groups + 63) / 64), dim3(64), 0, st, src, a.regions,
-                               a.group_prefix, a.n_regions, a.n_groups, a.exit_tbl, a.group_entry, a.tile_entry, a.str_index);
+                               a.group_prefix, a.n_regions, a.n_groups, a.exit_tbl, a.group_entry, a.tile_entry, a.str_index, gate_any);
             LAUNCH_CHECK();
         }
     } else if (a.n_tiles) {
         if constexpr (KIND == KIND_STRINGS)
             hipLaunchKernelGGL(k_str_mark, dim3((a.n_tiles + STR_MG - 1) / STR_MG), dim3(CH_THREADS), 0, st, src, a.regions,
-                               a.tile_prefix, a.n_regions, a.n_tiles, a.tile_entry, (const u32x4*)a.str_cp, page_dyn, a.tile_region, status);
+                               a.tile_prefix, a.n_regions, a.n_tiles, a.tile_entry, (const u32x4*)a.str_cp, page_dyn, a.tile_region, status, gate_any);
         else
             hipLaunchKernelGGL((k_chain<KIND, true, CHAIN_NT_MARK>), dim3(a.n_tiles), dim3(CHAIN_NT_MARK), 0, st, src, a.regions, a.tile_prefix,
                                a.n_regions, a.exit_tbl, a.tile_entry, run_tbl, otile_first_run, page_dyn, a.tile_region);
@@ -2336,6 +2751,19 @@ hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs
     if (kind == KIND_LEVELS) return launch_chain_t<KIND_LEVELS>(st, src, a, run_tbl, otile_first_run, page_dyn, status, phase);
     if (kind == KIND_SNAPPY) return launch_chain_t<KIND_SNAPPY>(st, src, a, run_tbl, otile_first_run, page_dyn, status, phase);
     return launch_chain_t<KIND_STRINGS>(st, src, a, run_tbl, otile_first_run, page_dyn, status, phase);
+}
+
+hipError_t launch_str_fused(hipStream_t st, const u8* src, const ChainArgs& a, PageDyn* str_pd) {
+    if (a.n_regions == 0) return hipSuccess;
+    if (a.n_units) {
+        hipLaunchKernelGGL(k_str_fused, dim3(a.n_units), dim3(SF_THREADS), 0, st, src, a.regions, a.unit_order, a.unit_region,
+                           a.str_stat, a.str_failed, a.str_any);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_str_totals, dim3((a.n_regions + 63) / 64), dim3(64), 0, st, a.regions, a.n_regions, a.str_stat,
+                       a.str_failed, a.totals, str_pd);
+    LAUNCH_CHECK();
+    return hipSuccess;
 }
 
 hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_region,
@@ -2397,9 +2825,9 @@ hipError_t launch_scatter(hipStream_t st, int width, bool offsets, const u8* val
 }
 
 hipError_t launch_str_page_scan(hipStream_t st, const Region* regions, const u32* region_prefix, u32 n_str_chunks,
-                                const RegionTotal* totals, PageDyn* str_pd) {
+                                const RegionTotal* totals, PageDyn* str_pd, const u32* gate) {
     if (n_str_chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_str_page_scan, dim3(n_str_chunks), dim3(64), 0, st, regions, region_prefix, n_str_chunks, totals, str_pd);
+    hipLaunchKernelGGL(k_str_page_scan, dim3(n_str_chunks), dim3(64), 0, st, regions, region_prefix, n_str_chunks, totals, str_pd, gate);
     LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -165,6 +165,10 @@ class Plan:
     def device_ptr(self, chunk, which):
         return N.decode.pqd_plan_device_ptr(self._h, chunk, which)
 
+    def string_fallbacks(self):
+        """BYTE_ARRAY chunks of the last synced run that the single pass gave up (decoded by the two passes instead)."""
+        return int(N.decode.pqd_plan_string_fallbacks(self._h))
+
     def fetch(self, chunk, which, dtype=np.uint8):
         ci = self.info(chunk)
         sizes = {
