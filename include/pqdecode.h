@@ -170,7 +170,7 @@ int64_t pqd_plan_string_fallbacks(pqd_plan* plan);
 
 /* Diagnostics: when the plan was created with PQD_LV_STAMPS set in the environment, the level kernel of the
  * last run left 16 wall-clock stamps (100 MHz) per workgroup; copies them to `dst` and returns the bytes
- * (0 when the plan has none). */
+ * (0 when the plan has none).  With PQD_STR_STAMPS set instead, the same for the single-pass string kernel. */
 int64_t pqd_plan_debug_stamps(pqd_plan* plan, void* dst, size_t cap);
 
 /* Convenience: host buffer in, results on device; = copy_to_device + plan_create + run + sync.

@@ -23,6 +23,7 @@ struct pqd_ctx {
     bool overlap = true;            // PQD_OVERLAP=0 keeps everything on one stream
     bool str_after_levels = false;  // PQD_STR_AFTER_LEVELS=1: diagnostics, see enqueue_run
     bool str_fused = true;          // PQD_STR_PATH=twopass: every string chunk through the two passes (the single pass's fallback)
+    bool str_giveup = false;        // PQD_STR_PATH=giveup: the single pass runs but finds every chunk given up already (tests of the hand-over)
     bool graph = false;             // PQD_GRAPH=1 replays chain batches as a captured HIP graph
     std::string err;
     u32 copy_grid = 0x7fffffffu;  // one block per 4 KiB tile; PQD_COPY_GRID caps it (then blocks grid-stride)
@@ -65,7 +66,8 @@ struct pqd_plan {
     std::vector<u32> bool_pages, btile_prefix, row_chunks, rtile_prefix;
     std::vector<u32> btile_owner, rtile_owner;  // per tile: its index into bool_pages / row_chunks (no search on the device)
     std::vector<u32> stile_region;  // region of every string chain tile
-    std::vector<u32> sunit_region, sunit_order;  // single string pass: region of every unit; launch order of the units
+    std::vector<u32> sunit_region;   // single string pass: region of every unit
+    std::vector<StrUnit> sunits;     // ... and the units in launch order
     std::vector<u32> vidx_pages;    // pages of the chunks that have definition levels
     std::vector<u64> page_lvl_off;  // level index of every page's first level within its chunk
     u32* d_vidx_pages = nullptr; u64* d_lvl_off = nullptr;
@@ -177,6 +179,7 @@ int pqd_create(int device, pqd_ctx** out) {
     if (sal) ctx->str_after_levels = atoi(sal) != 0;
     const char* sp = getenv("PQD_STR_PATH");
     if (sp) ctx->str_fused = strcmp(sp, "twopass") != 0;
+    if (sp) ctx->str_giveup = strcmp(sp, "giveup") == 0;
     const char* gr = getenv("PQD_GRAPH");
     if (gr) ctx->graph = atoi(gr) != 0;
     *out = ctx;
@@ -493,13 +496,18 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     {   // launch order of the units: the k-th unit of every chunk before the k+1-th of any, so that the units in flight
         // are spread over all chunks and a unit's predecessors in its chunk are few and old
         const size_t nu = pl->sunit_region.size();
-        pl->sunit_order.resize(nu);
+        pl->sunits.resize(nu);
         std::vector<std::pair<u32, u32>> key(nu);
         for (size_t u = 0; u < nu; u++) key[u] = {(u32)u - pl->sregions[pl->sunit_region[u]].lv_base, (u32)u};
         std::sort(key.begin(), key.end());
-        for (size_t u = 0; u < nu; u++) pl->sunit_order[u] = key[u].second;
+        for (size_t k = 0; k < nu; k++) {
+            const u32 u = key[k].second, r = pl->sunit_region[u];
+            const Region& R = pl->sregions[r];
+            const u32 tb0 = (u - R.count_level) * SF_TPU * CH_T;
+            pl->sunits[k] = StrUnit{R.src_off + tb0, tb0, R.len - tb0, r, u};
+        }
     }
-    const size_t o_suo = ap.take(pl->sunit_order.size() * 4), o_sur = ap.take(pl->sunit_region.size() * 4);
+    const size_t o_suo = ap.take(pl->sunits.size() * sizeof(StrUnit));
     const size_t o_sgp = ap.take(pl->sgroup_prefix.size() * 4);
     const size_t o_ssp = ap.take(pl->ssuper_prefix.size() * 4);
     const size_t o_bp = ap.take(pl->bool_pages.size() * 4);
@@ -523,6 +531,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_cdyn = ap.take(n_chunks * sizeof(ChunkDyn));
     const bool lv_stamps = getenv("PQD_LV_STAMPS") != nullptr;  // diagnostics: per-workgroup phase stamps of k_levels
     const size_t o_lvst = lv_stamps ? ap.take((size_t)pl->n_lvtiles * LV_STAMPS * 8) : 0;
+    const bool str_stamps = getenv("PQD_STR_STAMPS") != nullptr;  // diagnostics: per-workgroup phase stamps of k_str_fused
+    const size_t o_sfst = str_stamps ? ap.take(pl->sunit_region.size() * SF_STAMPS * 8) : 0;
     // reset to 0xFF every run
     const size_t o_ff = ap.total;
     const size_t o_ste = ap.take((size_t)pl->n_stiles_chain * sizeof(TileEntry));
@@ -652,8 +662,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         pl->schain.str_failed = (u32*)(A + o_sfail);
         pl->schain.str_any = (u32*)(A + o_sany);
         pl->schain.n_units = (u32)pl->sunit_region.size();
-        pl->schain.unit_order = (u32*)(A + o_suo);
-        pl->schain.unit_region = (u32*)(A + o_sur);
+        pl->schain.units = (StrUnit*)(A + o_suo);
+        pl->schain.str_stamps = str_stamps ? (u64*)(A + o_sfst) : nullptr;
     }
     pl->schain.str_index = StrIndex{(const unsigned short*)(A + o_scand),
                                     (const unsigned short*)(A + o_sncand), (unsigned short*)(A + o_sgpre), (unsigned short*)(A + o_sspre)};
@@ -670,8 +680,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if ((rc = upload(ctx, pl->d_lvl_off, pl->page_lvl_off))) return rc;
     if ((rc = upload(ctx, pl->d_stile_chain_prefix, pl->stile_chain_prefix))) return rc;
     if ((rc = upload(ctx, (u32*)(A + o_str), pl->stile_region))) return rc;
-    if ((rc = upload(ctx, (u32*)(A + o_suo), pl->sunit_order))) return rc;
-    if ((rc = upload(ctx, (u32*)(A + o_sur), pl->sunit_region))) return rc;
+    if ((rc = upload(ctx, (StrUnit*)(A + o_suo), pl->sunits))) return rc;
     if ((rc = upload(ctx, pl->d_sgroup_prefix, pl->sgroup_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_ssuper_prefix, pl->ssuper_prefix))) return rc;
     if ((rc = upload(ctx, pl->d_bool_pages, pl->bool_pages))) return rc;
@@ -706,6 +715,10 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     if (pl->n_stiles_chain)
         HIP_TRY(ctx, hipMemsetAsync(pl->ff_begin, 0xFF, pl->ff_bytes, st));
     HIP_TRY(ctx, hipMemsetAsync(pl->zero_begin, 0, pl->zero_bytes, st));
+    if (ctx->str_giveup && pl->schain.str_failed) {
+        HIP_TRY(ctx, hipMemsetAsync(pl->schain.str_failed, 1, (pl->str_chunk_prefix.size() - 1) * 4, st));
+        HIP_TRY(ctx, hipMemsetAsync(pl->schain.str_any, 1, 4, st));
+    }
 
     // Three streams.  The PLAIN value gather is independent of the levels (the reference reads the concatenated
     // values regions as one stream) and HBM-bound, while the level and string kernels are instruction-bound, so
@@ -935,6 +948,13 @@ int64_t pqd_plan_string_fallbacks(pqd_plan* pl) {
 }
 
 int64_t pqd_plan_debug_stamps(pqd_plan* pl, void* dst, size_t cap) {
+    if (pl && !pl->lv.stamps && pl->schain.str_stamps) {  // PQD_STR_STAMPS without PQD_LV_STAMPS: the string kernel's stamps
+        const size_t n = (size_t)pl->schain.n_units * SF_STAMPS * 8;
+        if (n > cap || !dst) return PQD_E_ARG;
+        HIP_TRY(pl->ctx, hipSetDevice(pl->ctx->device));
+        HIP_TRY(pl->ctx, hipMemcpy(dst, pl->schain.str_stamps, n, hipMemcpyDeviceToHost));
+        return (int64_t)n;
+    }
     if (!pl || !pl->lv.stamps) return 0;
     const size_t n = (size_t)pl->n_lvtiles * LV_STAMPS * 8;
     if (n > cap || !dst) return PQD_E_ARG;

@@ -117,6 +117,14 @@ struct StrIndex {
     unsigned short* gpre;        // n_tiles: plausible positions in the earlier tiles of the tile's group (k_chain_groups)
     unsigned short* spre;        // n_tiles: ... of the tile's super-group (k_chain_supers)
 };
+// strings, single pass: SF_TPU tiles of one page, decoded by one workgroup
+struct StrUnit {
+    u64 src_off;  // source offset of the unit's first byte
+    u32 tb0;      // page position of that byte
+    u32 rem;      // bytes from there to the end of the page
+    u32 region;   // the page's string region
+    u32 ui;       // index of the unit in page order within its chunk (its status word)
+};
 struct ChainArgs {
     const Region* regions;
     const u32* tile_prefix;   // n_regions + 1
@@ -137,8 +145,8 @@ struct ChainArgs {
     // strings, single pass (k_str_fused): null = the two passes decode every chunk
     u64* str_stat;            // n_units status words {state, strings, exit}; zero before every run
     u32 n_units;              // units of SF_TPU tiles of one page
-    const u32* unit_order;    // launch order: the k-th unit of every chunk before the k+1-th of any
-    const u32* unit_region;   // n_units
+    const StrUnit* units;     // n_units, in launch order: the k-th unit of every chunk before the k+1-th of any
+    u64* str_stamps;          // diagnostics only (else null): SF_STAMPS wall-clock stamps (100 MHz) per workgroup of k_str_fused
     u32* str_failed;          // one word per BYTE_ARRAY chunk, zero before every run: set = the chunk goes through the two passes
     u32* str_any;             // one word, zero before every run: set when any chunk was given up
 };
@@ -149,10 +157,11 @@ hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs
 // Region fields on this path: count_level = first unit of the region, lv_base = first unit of the region's chunk,
 // run_base = bytes of the chunk's earlier pages (values regions), width = entries of the chunk's offsets array,
 // otile_base = index of the chunk among the BYTE_ARRAY chunks.
-constexpr u32 SF_WAVES = 16, SF_TPW = 2;       // waves per workgroup (unit), tiles per wave
+constexpr u32 SF_WAVES = 4, SF_TPW = 2;        // waves per workgroup (unit), tiles per wave
 constexpr u32 SF_TPU = SF_WAVES * SF_TPW;      // tiles per unit
 constexpr u32 SF_REP_MAX = 2;                  // tiles of a unit that may be walked string by string
 static_assert(SF_TPU <= 64, "one lane per tile of a unit");
+constexpr u32 SF_STAMPS = 16;
 hipError_t launch_str_fused(hipStream_t st, const u8* src, const ChainArgs& a, PageDyn* str_pd);
 // otile_region: region of every expand tile plus one spare entry (may be null: the kernel then searches
 // otile_prefix); otile_first_run must have one spare entry after its n_otiles.

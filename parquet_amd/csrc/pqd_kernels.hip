@@ -17,6 +17,7 @@
 //   k_rows_*          per-row level consumption of the generated write functions
 //                     (cmd/parquetgen/dremel/write_repeated.go:62-80, write_optional.go:22-31)
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
 
@@ -894,17 +895,13 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_exits(const u8* __restrict__
 // and gives its place to the tile's compaction buffer afterwards.
 constexpr u32 STR_MG = 2;
 static_assert(CH_T + 16 <= STR_LDS_WORDS * 4, "the compaction buffer reuses the tile image");
-__global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ src_base, const Region* __restrict__ regions,
-                                                         const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
-                                                         const TileEntry* __restrict__ tile_entry,
-                                                         const u32x4* __restrict__ str_cp,
-                                                         const PageDyn* __restrict__ page_dyn, const u32* __restrict__ tile_region,
-                                                         const int* __restrict__ status, const u32* __restrict__ gate_any) {
-    if (gate_any && !*gate_any) return;  // behind the single pass: only tiles of the chunks it gave up have entries
-    if (status && status[0]) return;  // an earlier kernel found the batch corrupt: value counts and offsets are not to be trusted
+static __device__ __forceinline__ void str_mark_tiles(u32 t0, const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                                                      const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
+                                                      const TileEntry* __restrict__ tile_entry, const u32x4* __restrict__ str_cp,
+                                                      const PageDyn* __restrict__ page_dyn, const u32* __restrict__ tile_region) {
     __shared__ __attribute__((aligned(16))) u32 s_buf[STR_MG][STR_LDS_WORDS];
     __shared__ u32 s_bits[STR_MG][64], s_last[STR_MG][2];
-    const u32 lane = threadIdx.x, t0 = blockIdx.x * STR_MG;
+    const u32 lane = threadIdx.x;
     // loads that do not depend on each other are issued together: entries and region indices, then the regions,
     // the entries' checkpoint rows and the pages' offsets
     u32 epos[STR_MG], ecnt[STR_MG], eslot[STR_MG], ri[STR_MG];
@@ -1071,6 +1068,21 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
         }
     }
 }
+// Behind the single pass (gate_any given) the launch is a small grid whose workgroups loop over the tiles: nearly
+// always no chunk was given up and every workgroup ends at once.
+__global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ src_base, const Region* __restrict__ regions,
+                                                         const u32* __restrict__ tile_prefix, u32 n_regions, u32 n_tiles,
+                                                         const TileEntry* __restrict__ tile_entry,
+                                                         const u32x4* __restrict__ str_cp,
+                                                         const PageDyn* __restrict__ page_dyn, const u32* __restrict__ tile_region,
+                                                         const int* __restrict__ status, const u32* __restrict__ gate_any) {
+    if (gate_any && !*gate_any) return;  // only tiles of the chunks that were given up have entries
+    if (status && status[0]) return;  // an earlier kernel found the batch corrupt: value counts and offsets are not to be trusted
+    for (u32 t0 = blockIdx.x * STR_MG; t0 < n_tiles; t0 += gridDim.x * STR_MG) {
+        str_mark_tiles(t0, src_base, regions, tile_prefix, n_regions, n_tiles, tile_entry, str_cp, page_dyn, tile_region);
+        __syncthreads();  // the next tiles reuse the LDS
+    }
+}
 
 // =====================================================================================
 // k_str_fused — the strings of a page batch in ONE pass over the page bytes (template_string.go:47-58,
@@ -1106,30 +1118,68 @@ constexpr u32 SF_PASS = 0xFFFFFFFDu;       // exit of a tile (unit) in which no 
 constexpr u32 SF_CNT_MAX = (1u << 28) - 1; // strings of a chunk that the status word can count
 constexpr u64 SF_TIMEOUT = 2000000;        // wall-clock ticks (100 MHz) a unit waits for the units before it: 20 ms
 constexpr u32 SF_THREADS = SF_WAVES * 64;
-static __device__ __forceinline__ u64 sf_pack(u64 state, u32 cnt, u32 exit) { return state << 62 | (u64)cnt << 32 | exit; }
+// status word of a unit: state (2 bits) | spill (2) | strings (28) | exit (32).  spill = bytes of the length prefix of the
+// unit's last string that lie behind the unit's end (the next unit's first bytes are those, not chars)
+static __device__ __forceinline__ u64 sf_pack(u64 state, u32 spill, u32 cnt, u32 exit) {
+    return state << 62 | (u64)spill << 60 | (u64)cnt << 32 | exit;
+}
 static __device__ __forceinline__ u64 sf_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static __device__ __forceinline__ void sf_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-static __device__ __forceinline__ u32 sf_wave_sum(u32 v) {
-#pragma unroll
-    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+// Inclusive prefix sum over the 64 lanes of a wave in six DPP additions (shifts inside rows of 16 lanes, then the row
+// totals broadcast upwards): no LDS crossbar round trips as with six shuffles.
+template <int CTRL, int ROW_MASK>
+static __device__ __forceinline__ u32 sf_dpp(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false); }
+static __device__ __forceinline__ u32 sf_wave_scan(u32 v) {
+    v += sf_dpp<0x111, 0xf>(v);  // row_shr:1
+    v += sf_dpp<0x112, 0xf>(v);  // row_shr:2
+    v += sf_dpp<0x114, 0xf>(v);  // row_shr:4
+    v += sf_dpp<0x118, 0xf>(v);  // row_shr:8
+    v += sf_dpp<0x142, 0xa>(v);  // row_bcast:15: lane 15 -> row 1, lane 47 -> row 3
+    v += sf_dpp<0x143, 0xc>(v);  // row_bcast:31: lane 31 -> rows 2 and 3
     return v;
 }
+static __device__ __forceinline__ u32 sf_wave_sum(u32 v) { return (u32)__builtin_amdgcn_readlane((int)sf_wave_scan(v), 63); }
+// Bit k of the result: the four bytes at byte k of the lane's 36-byte window W (nine little-endian words) are a number
+// below 2^20, i.e. the 16-bit number at byte k + 2 is below 16.  Those lie in the halves of W's words (even k) and of
+// the words shifted by one byte (odd k); one compare on a half word and one add-with-carry (c = 2 c + carry) per position.
+static __device__ __forceinline__ u32 sf_small_mask(const u32 (&W)[9]) {
+    u32 y[9];
+#pragma unroll
+    for (int d = 0; d < 8; d++) y[d] = __builtin_amdgcn_alignbit(W[d + 1], W[d], 8);  // bytes 4d+1 .. 4d+4
+    y[8] = W[8] >> 8;                                                                // bytes 33 .. 35
+    u32 c = 0;
+    const u32 k16 = 16;
+#pragma unroll
+    for (int d = 7; d >= 0; d--)  // positions 4d+3, 4d+2, 4d+1, 4d: half words at bytes 4d+5, 4d+4, 4d+3, 4d+2
+        asm("v_cmp_gt_u32_sdwa vcc, %[k], %[yn] src0_sel:DWORD src1_sel:WORD_0\n\t"
+            "v_addc_co_u32_e32 %[c], vcc, %[c], %[c], vcc\n\t"
+            "v_cmp_gt_u32_sdwa vcc, %[k], %[wn] src0_sel:DWORD src1_sel:WORD_0\n\t"
+            "v_addc_co_u32_e32 %[c], vcc, %[c], %[c], vcc\n\t"
+            "v_cmp_gt_u32_sdwa vcc, %[k], %[yd] src0_sel:DWORD src1_sel:WORD_1\n\t"
+            "v_addc_co_u32_e32 %[c], vcc, %[c], %[c], vcc\n\t"
+            "v_cmp_gt_u32_sdwa vcc, %[k], %[wd] src0_sel:DWORD src1_sel:WORD_1\n\t"
+            "v_addc_co_u32_e32 %[c], vcc, %[c], %[c], vcc"
+            : [c] "+v"(c)
+            : [k] "v"(k16), [yn] "v"(y[d + 1]), [wn] "v"(W[d + 1]), [yd] "v"(y[d]), [wd] "v"(W[d])
+            : "vcc");
+    return c;
+}
 
-// What the units in front of unit `ui` say (one wave): strings in front of it within its chunk (units cf..ui-1) and the
-// exit of the nearest unit in front of it in its page that has one (0 for a page's first unit, rf).  False: the chunk
-// was given up (by another unit, or here because the wait ran out).
+// What the units in front of unit `ui` say (one wave): strings in front of it within its chunk (units cf..ui-1), the
+// exit of the nearest unit in front of it in its page that has one (0 for a page's first unit, rf), and the spill of the
+// unit right in front of it.  False: the chunk was given up (by another unit, or here because the wait ran out).
 static __device__ __forceinline__ bool sf_lookback(const u64* __restrict__ ustat, u32 ui, u32 cf, u32 rf, const u32* chunk_failed,
-                                                   u32 lane, u32& excl, u32& pexit) {
-    excl = 0;
+                                                   u32 lane, u32& excl, u32& pexit, u32& pspill) {
+    excl = 0; pspill = 0;
     bool have_exit = ui == rf;
     pexit = 0;
-    bool counted = false;
+    bool counted = false, first = true;
     long long base = ui;
     u64 t_start = 0;
     while (true) {
         const long long j = base - 1 - (long long)lane;
         const bool valid = j >= (long long)cf;
-        const u64 wd = valid ? sf_load(ustat + j) : sf_pack(SF_INCL, 0, 0);  // in front of the chunk: an empty prefix
+        const u64 wd = valid ? sf_load(ustat + j) : sf_pack(SF_INCL, 0, 0, 0);  // in front of the chunk: an empty prefix
         const u32 st = (u32)(wd >> 62);
         const u64 m_incl = __ballot(st == SF_INCL), m_nr = __ballot(st == 0);
         if (__ballot(st == SF_FAIL)) return false;
@@ -1140,10 +1190,12 @@ static __device__ __forceinline__ bool sf_lookback(const u64* __restrict__ ustat
             const u64 now = wall_clock64();
             if (!t_start) t_start = now;
             else if (now - t_start > SF_TIMEOUT) return false;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             continue;
         }
         if (!counted) excl += sf_wave_sum(lane <= fi ? (u32)(wd >> 32) & SF_CNT_MAX : 0);
+        if (first && ui > rf) pspill = (u32)((u64)__builtin_amdgcn_readfirstlane((int)(wd >> 32)) >> 28) & 3;  // lane 0: unit ui - 1, same page
+        first = false;
         if (!have_exit) {
             const u64 mc = __ballot(lane <= fi && j >= (long long)rf && (u32)wd != SF_PASS);
             if (mc) {
@@ -1159,57 +1211,60 @@ static __device__ __forceinline__ bool sf_lookback(const u64* __restrict__ ustat
 }
 
 __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__ src_base, const Region* __restrict__ regions,
-                                                          const u32* __restrict__ unit_order, const u32* __restrict__ unit_region,
+                                                          const StrUnit* __restrict__ units,
                                                           u64* __restrict__ ustat, u32* __restrict__ chunk_failed,
-                                                          u32* __restrict__ any_failed) {
+                                                          u32* __restrict__ any_failed, u64* __restrict__ stamps) {
     constexpr u32 NT = SF_TPW;
+    constexpr u32 BAD = 0xFFFFFFFFu;  // s_cnt of a tile whose guess did not prove itself
+#define SF_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(u64)blockIdx.x * SF_STAMPS + (i)] = wall_clock64(); } while (0)
+    SF_STAMP(0);
     __shared__ __attribute__((aligned(16))) u32 s_buf[SF_TPU][STR_LDS_WORDS];
-    __shared__ u32 s_cnt[SF_TPU], s_ent[SF_TPU], s_ext[SF_TPU], s_lastq[SF_TPU], s_excl[SF_TPU], s_epos[SF_TPU], s_slot[SF_TPU];
+    __shared__ u32 s_cnt[SF_TPU], s_ent[SF_TPU], s_ext[SF_TPU], s_spill[SF_TPU], s_excl[SF_TPU], s_slot[SF_TPU];
     __shared__ u32 s_bits[SF_REP_MAX][64];
-    __shared__ u32 s_alive;
+    __shared__ u32 s_alive, s_spin0;
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const u32 ui = unit_order[blockIdx.x];
-    const Region R = regions[unit_region[ui]];
-    const u32 L = R.len;
-    const u32 k0 = (ui - R.count_level) * SF_TPU;      // the unit's first tile within its page
-    const u32 n_on = (L - k0 * CH_T + CH_T - 1) / CH_T < SF_TPU ? (L - k0 * CH_T + CH_T - 1) / CH_T : SF_TPU;  // its tiles (>= 1)
-    const u8* const rsrc = src_base + R.src_off;
+    // Workgroup b takes unit b of the launch order (a workgroup that took several units in turn, with the next unit's bytes
+    // requested ahead, was tried: whatever hands the units out, one shared counter, eight of them or a fixed stride,
+    // costs more in waits for units in front than the requests ahead save).  One table entry says where the unit's bytes
+    // lie: the tiles are requested at once, the page's record comes beside them.
+    const StrUnit U = units[blockIdx.x];
+    const u32 ui = U.ui;
+    const u32 n_on = (U.rem + CH_T - 1) / CH_T < SF_TPU ? (U.rem + CH_T - 1) / CH_T : SF_TPU;  // the unit's tiles (>= 1)
     bool on[NT];
-    u32 tb[NT], lim[NT], rlim[NT];
+    u32 tb[NT], rem[NT], rlim[NT];
     u32 w[NT][8];
 #pragma unroll
     for (u32 t = 0; t < NT; t++) {
         const u32 tu = wv * NT + t;
         on[t] = tu < n_on;
-        tb[t] = (k0 + tu) * CH_T;
-        lim[t] = tb[t] + CH_T < L ? tb[t] + CH_T : L;
-        rlim[t] = on[t] ? lim[t] - tb[t] : 0;
-        if (on[t]) str_stage_tile(rsrc, L, tb[t], lane, w[t], s_buf[tu]);
+        tb[t] = U.tb0 + tu * CH_T;                    // page position of the tile
+        rem[t] = on[t] ? U.rem - tu * CH_T : 0;       // bytes from the tile's start to the end of the page
+        rlim[t] = rem[t] < CH_T ? rem[t] : CH_T;      // bytes of the tile
+        if (on[t]) str_stage_tile(src_base + U.src_off + (u64)tu * CH_T, rem[t], 0, lane, w[t], s_buf[tu]);
     }
+    const Region R = regions[U.region];
     __builtin_amdgcn_wave_barrier();  // a wave reads only the tile images it wrote itself until the first barrier
+    if (stamps && threadIdx.x == 0) { if (s_buf[0][0] == 0x12345678u) stamps[0] = 1; SF_STAMP(1); }  // the read waits for the tile's bytes
 
-    // ---- guess and proof inside each tile
-    u32 S[NT], cnt[NT], ext[NT], lastq[NT];
-    bool ok[NT];
+    // ---- guess and proof inside each tile (positions relative to the tile)
+    u32 S[NT];
 #pragma unroll
     for (u32 t = 0; t < NT; t++) {
         const u32 tu = wv * NT + t;
-        S[t] = 0; cnt[t] = 0; ext[t] = SF_PASS; lastq[t] = ERR_POS; ok[t] = true;
+        S[t] = 0;
         if (!on[t]) continue;
         const u32* const tl = s_buf[tu];
         const u32 la = tl[CH_T / 4];  // the four bytes behind the tile
         u32 nw = __shfl_down(w[t][0], 1);
         if (lane == 63) nw = la;
         const u32 W9[9] = {w[t][0], w[t][1], w[t][2], w[t][3], w[t][4], w[t][5], w[t][6], w[t][7], nw};
-        u32 C = 0;
-        if ((u64)tb[t] + CH_T + 4 + STR_CAND_MAX <= L) {  // every position of the tile has STR_CAND_MAX bytes of page behind it
-#pragma unroll
-            for (int k = 31; k >= 0; k--) {
-                const u32 x = (k & 3) ? __builtin_amdgcn_alignbit(W9[k / 4 + 1], W9[k / 4], (k & 3) * 8) : W9[k / 4];
-                C = (C << 1) | (u32)(x < STR_CAND_MAX);
-            }
+        u32 C;
+        static_assert(STR_CAND_MAX == 1u << 20, "sf_small_mask tests for lengths below 2^20");
+        if (rem[t] >= CH_T + 4 + STR_CAND_MAX) {  // every position of the tile has STR_CAND_MAX bytes of page behind it
+            C = sf_small_mask(W9);
         } else {
-            const int room0 = (int)L - 3 - (int)(tb[t] + lane * CH_SUB);
+            C = 0;
+            const int room0 = (int)rem[t] - 3 - (int)(lane * CH_SUB);
 #pragma unroll
             for (int k = 31; k >= 0; k--) {
                 const u32 x = (k & 3) ? __builtin_amdgcn_alignbit(W9[k / 4 + 1], W9[k / 4], (k & 3) * 8) : W9[k / 4];
@@ -1217,7 +1272,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
             }
         }
         u32 c_next = __shfl_down(C, 1) & 1;
-        if (lane == 63) c_next = la < str_cand_room((int)L - 3 - (int)(tb[t] + CH_T));
+        if (lane == 63) c_next = la < str_cand_room((int)rem[t] - 3 - (int)CH_T);
         const u32 Sm = C & ~((C >> 1) | (c_next << 31));
         // the first guessed start in the lanes above mine, and of the tile
         u32 v = Sm ? lane * CH_SUB + (u32)__ffs(Sm) - 1 : 0xFFFFu;
@@ -1228,7 +1283,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
         }
         u32 nf = __shfl_down(v, 1);
         if (lane == 63) nf = 0xFFFFu;
-        const u32 ent = __shfl(v, 0);
+        const u32 ent = (u32)__builtin_amdgcn_readfirstlane((int)v);
         bool good = true;
         u32 my_exit = 0, my_last = 0xFFFFu, m = Sm;
         while (__any(m != 0)) {
@@ -1242,44 +1297,83 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
                 else good = good && nx == succ;
             }
         }
-        ok[t] = __all(good);
+        const bool ok = __all(good);
         S[t] = Sm;
-        cnt[t] = sf_wave_sum(__popc(Sm));
+        const u32 cnt = sf_wave_sum(__popc(Sm));
         const u64 bl = __ballot(my_last != 0xFFFFu);  // the lane of the tile's last start, if it has one
+        u32 ext = SF_PASS, spill = 0;
         if (bl) {
             const int l = __ffsll((unsigned long long)bl) - 1;
-            ext[t] = tb[t] + __shfl(my_exit, l);
-            lastq[t] = tb[t] + __shfl(my_last, l);
+            ext = tb[t] + __shfl(my_exit, l);
+            const u32 lq = __shfl(my_last, l);
+            spill = lq + 4 > rlim[t] ? lq + 4 - rlim[t] : 0;
         }
         if (lane == 0) {
-            s_cnt[tu] = ok[t] ? cnt[t] : 0xFFFFFFFFu;  // 0xFFFFFFFF: the guess did not prove itself
+            s_cnt[tu] = ok ? cnt : BAD;
             s_ent[tu] = tb[t] + ent;
-            s_ext[tu] = ext[t];
-            s_lastq[tu] = lastq[t];
+            s_ext[tu] = ext;
+            s_spill[tu] = spill;
+            s_slot[tu] = BAD;
         }
     }
+    SF_STAMP(2);
     __syncthreads();
+    SF_STAMP(3);
+    const bool all_ok = !__ballot(lane < n_on && s_cnt[lane < n_on ? lane : 0] == BAD);  // the same in every wave
 
-    // ---- the unit: ranks, the proof between tiles, repairs (wave 0)
+    // ---- offsets and chars of a tile, in two steps.  Every byte of a tile that is no length byte is a char (the bytes in
+    // front of its first start are the tail of the string that enters it), so a tile moves exactly its own bytes.
+    // Step 1 needs the tile's starts and the spill of the tile before it, nothing from other units: the chars are compacted
+    // into the tile's LDS image.  Step 2 needs the rank of the tile's first string: string number g at stream position q
+    // has its chars at q - 4 g, so the tile's chars go to (stream position of the tile) + spill - 4 (strings before it).
+    u32 n_chars[NT], a3[NT], ps[NT];
+    auto compact = [&](u32 t, u32 spill_in) {
+        const u32 tu = wv * NT + t;
+        const u32 smask = S[t];
+        u32 prev = __shfl_up(smask, 1);
+        if (lane == 0) prev = 0;
+        u32 lenmask = smask | (smask << 1) | (smask << 2) | (smask << 3) | ((prev >> 29) & 1) | (((prev >> 30) & 1) * 3) |
+                      (((prev >> 31) & 1) * 7);
+        if (lane == 0) lenmask |= (1u << spill_in) - 1;
+        const u32 sub_lo = lane * CH_SUB;
+        const u32 k_hi = rlim[t] >= sub_lo + CH_SUB ? 32 : rlim[t] <= sub_lo ? 0 : rlim[t] - sub_lo;
+        const u32 own = k_hi >= 32 ? 0xFFFFFFFFu : (1u << k_hi) - 1;
+        const u32 charmask = own & ~lenmask;
+        const u32 mine = __popc(charmask) | (__popc(smask) << 16);
+        const u32 incl = sf_wave_scan(mine);
+        n_chars[t] = (u32)__builtin_amdgcn_readlane((int)incl, 63) & 0xFFFF;
+        const u32 pc = (incl - mine) & 0xFFFF;
+        ps[t] = (incl - mine) >> 16;
+        // the chars keep their place within a 4-byte word of the destination whatever the rank turns out to be (it moves
+        // them by a multiple of 4): byte i of the tile's chars goes to byte a3 + i of the image
+        a3[t] = (u32)((uintptr_t)R.out2 + R.run_base + tb[t] + spill_in) & 3;
+        u8* const stage = (u8*)s_buf[tu];  // every read of the tile image is over
+#pragma unroll
+        for (int k = 0; k < (int)CH_SUB; k++)
+            if ((charmask >> k) & 1) stage[a3[t] + pc + __popc(charmask & ((1u << k) - 1))] = (u8)(w[t][k >> 2] >> (8 * (k & 3)));
+    };
+
+    // ---- the unit: ranks, the proof between tiles, repairs (wave 0), while the other waves compact their chars
     if (wv == 0) {
         const bool mine = lane < n_on;
         u32 c = mine ? s_cnt[lane] : 0, e = mine ? s_ext[lane] : SF_PASS;
         const u32 en = mine ? s_ent[lane] : 0;
-        const u32 t_lim = (k0 + lane + 1) * CH_T < L ? (k0 + lane + 1) * CH_T : L;
-        const bool all_ok = !__ballot(c == 0xFFFFFFFFu);
+        const u32 t_lim = U.tb0 + ((lane + 1) * CH_T < U.rem ? (lane + 1) * CH_T : U.rem);
         const u32 cf = R.lv_base, rf = R.count_level;
         u32* const cfail = chunk_failed + R.otile_base;
-        // the last tile with an exit of its own, if any
-        const u64 m_ex = __ballot(mine && e != SF_PASS);
+        const u64 m_ex = __ballot(mine && e != SF_PASS);  // tiles with an exit of their own
         u32 tot = 0, uexit = SF_PASS;
+        const u32 uspill0 = s_spill[n_on - 1];
         if (all_ok) {
             tot = sf_wave_sum(c);
             if (m_ex) uexit = __shfl(e, 63 - (int)__clzll((unsigned long long)m_ex));
-            if (lane == 0) sf_store(ustat + ui, sf_pack(SF_AGG, tot, uexit));
+            if (lane == 0) sf_store(ustat + ui, sf_pack(SF_AGG, uspill0, tot, uexit));
         }
-        u32 uexcl = 0, pexit = 0;
-        bool alive = sf_lookback(ustat, ui, cf, rf, cfail, lane, uexcl, pexit);
-        u32 epos = ERR_POS, slot = 0xFFFFFFFFu;
+        u32 uexcl = 0, pexit = 0, pspill = 0;
+        SF_STAMP(4);
+        bool alive = sf_lookback(ustat, ui, cf, rf, cfail, lane, uexcl, pexit, pspill);
+        SF_STAMP(5);
+        u32 uspill = uspill0;
         if (alive && all_ok) {
             // the exit of the nearest tile in front of mine that has one (else the unit's predecessor's)
             const u64 below = m_ex & ((1ull << lane) - 1);
@@ -1287,30 +1381,26 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
             const u32 pe = below ? e_below : pexit;
             const bool bad = mine && (c ? en != pe : pe < t_lim);
             if (__ballot(bad)) alive = false;
-            if (c) epos = pe;
             if (uexit == SF_PASS) uexit = pexit;
         } else if (alive) {
             // some guess failed: one lane goes through the tiles in order and walks the failed ones string by string
             if (lane == 0) {
                 u32 pe = pexit, nrep = 0;
                 for (u32 t = 0; t < n_on && alive; t++) {
-                    const u32 tbt = (k0 + t) * CH_T, limt = tbt + CH_T < L ? tbt + CH_T : L;
+                    const u32 tbt = U.tb0 + t * CH_T, remt = U.rem - t * CH_T, rend = remt < CH_T ? remt : CH_T, limt = tbt + rend;
                     const u32 ct = s_cnt[t];
-                    s_slot[t] = 0xFFFFFFFFu;
-                    if (ct != 0xFFFFFFFFu) {
+                    if (ct != BAD) {
                         if (ct ? s_ent[t] != pe : pe < limt) { alive = false; break; }
-                        s_epos[t] = ct ? pe : ERR_POS;
                         if (ct) pe = s_ext[t];
                         continue;
                     }
                     if (nrep == SF_REP_MAX) { alive = false; break; }
-                    u32 n = 0, lastq = ERR_POS;
+                    u32 n = 0, spill = 0;
+                    u32* const bits = s_bits[nrep];
+                    for (u32 i = 0; i < 64; i++) bits[i] = 0;
                     if (pe < limt) {
-                        u32* const bits = s_bits[nrep];
-                        for (u32 i = 0; i < 64; i++) bits[i] = 0;
                         const u32* const tl = s_buf[t];
-                        const u32 avail = L - tbt, room0 = avail - 3, rend = limt - tbt;
-                        const u32 rend4 = avail < 4 ? 0 : rend < room0 ? rend : room0;
+                        const u32 room0 = remt - 3, rend4 = remt < 4 ? 0 : rend < room0 ? rend : room0;
                         u32 rel = pe - tbt, last_rel = rel;
                         while (rel < rend4) {
                             bits[rel >> 5] |= 1u << (rel & 31);
@@ -1321,14 +1411,13 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
                         }
                         if (rel < rend) rel = ERR_POS;  // a start in the last three bytes of the page
                         if (rel == ERR_POS) { alive = false; break; }  // a bad length: the two passes report it
-                        s_slot[t] = nrep++;
-                        s_epos[t] = pe;
-                        lastq = tbt + last_rel;
+                        spill = last_rel + 4 > rend ? last_rel + 4 - rend : 0;
                         pe = tbt + rel;
                         s_ext[t] = pe;
-                    } else s_epos[t] = ERR_POS;
+                    }
+                    s_slot[t] = nrep++;
                     s_cnt[t] = n;
-                    s_lastq[t] = lastq;
+                    s_spill[t] = spill;
                 }
                 uexit = pe;
             }
@@ -1336,80 +1425,65 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
             uexit = __shfl(uexit, 0);
             if (alive) {
                 c = mine ? s_cnt[lane] : 0;
-                epos = mine ? s_epos[lane] : ERR_POS;
-                slot = mine ? s_slot[lane] : 0xFFFFFFFFu;
                 tot = sf_wave_sum(c);
+                uspill = s_spill[n_on - 1];
             }
         }
         if (alive && (u64)uexcl + tot > SF_CNT_MAX) alive = false;
         if (alive) {
-            u32 incl = c;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const u32 y = __shfl_up(incl, d);
-                if (lane >= (u32)d) incl += y;
-            }
-            if (mine) { s_excl[lane] = uexcl + incl - c; s_epos[lane] = epos; s_cnt[lane] = c; s_slot[lane] = slot; }
-            if (lane == 0) sf_store(ustat + ui, sf_pack(SF_INCL, uexcl + tot, uexit));
+            const u32 incl = sf_wave_scan(c);
+            if (mine) s_excl[lane] = uexcl + incl - c;
+            if (lane == 0) { sf_store(ustat + ui, sf_pack(SF_INCL, uspill, uexcl + tot, uexit)); s_spin0 = pspill; }
         } else if (lane == 0) {
             __hip_atomic_store(cfail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(any_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sf_store(ustat + ui, sf_pack(SF_FAIL, 0, 0));
+            sf_store(ustat + ui, sf_pack(SF_FAIL, 0, 0, 0));
         }
         if (lane == 0) s_alive = alive;
+        SF_STAMP(6);
+        if (alive && all_ok) {
+#pragma unroll
+            for (u32 t = 0; t < NT; t++)
+                if (on[t]) compact(t, t == 0 ? pspill : s_spill[t - 1]);
+        }
+    } else if (all_ok) {
+#pragma unroll
+        for (u32 t = 0; t < NT; t++)
+            if (on[t]) compact(t, s_spill[wv * NT + t - 1]);
     }
     __syncthreads();
     if (!s_alive) return;
-
-    // ---- offsets and chars (as in k_str_mark): string number g starting at stream position q has its chars at q - 4 g
-    u32 n_chars[NT], pad[NT], excl[NT], epos[NT];
-    u8* cdst[NT];
-    bool emit[NT];
+    SF_STAMP(7);
+    if (!all_ok) {  // after a repair: the starts of a walked tile come from the walk
+#pragma unroll
+        for (u32 t = 0; t < NT; t++) {
+            const u32 tu = wv * NT + t;
+            if (!on[t]) continue;
+            if (s_slot[tu] != BAD) S[t] = s_bits[s_slot[tu]][lane];
+            compact(t, tu == 0 ? s_spin0 : s_spill[tu - 1]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    SF_STAMP(8);
 #pragma unroll
     for (u32 t = 0; t < NT; t++) {
+        if (!on[t]) continue;
         const u32 tu = wv * NT + t;
-        n_chars[t] = 0; pad[t] = 0; cdst[t] = nullptr; excl[t] = 0; epos[t] = ERR_POS;
-        emit[t] = on[t] && s_cnt[tu] > 0;
-        if (!emit[t]) continue;
-        excl[t] = s_excl[tu]; epos[t] = s_epos[tu];
-        if (s_slot[tu] != 0xFFFFFFFFu) {  // walked string by string
-            S[t] = s_bits[s_slot[tu]][lane];
-            ext[t] = s_ext[tu]; lastq[t] = s_lastq[tu];
-        }
-        const u64 q0 = R.run_base + epos[t];  // stream position of the tile's first start
-        if (q0 < 4ull * excl[t]) {  // only a rank from a wrong guess elsewhere can do this: the chunk is being given up
-            emit[t] = false;
+        const u32 excl = s_excl[tu];
+        const u32 spin = tu == 0 ? s_spin0 : s_spill[tu - 1];
+        const u64 q0 = R.run_base + tb[t] + spin;  // stream position of the tile's first byte that is no spilled length byte
+        if (q0 < 4ull * excl) {  // only a rank from a wrong guess elsewhere can do this: the chunk is being given up
             if (lane == 0) {
                 __hip_atomic_store(chunk_failed + R.otile_base, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(any_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             continue;
         }
-        const u32 sub_lo = tb[t] + lane * CH_SUB, sub_hi = sub_lo + CH_SUB;
-        const u32 smask = S[t];
-        u32 prev = __shfl_up(smask, 1);
-        if (lane == 0) prev = 0;
-        const u32 lenmask = smask | (smask << 1) | (smask << 2) | (smask << 3) | ((prev >> 29) & 1) | (((prev >> 30) & 1) * 3) |
-                            (((prev >> 31) & 1) * 7);
-        const u32 k_lo = epos[t] <= sub_lo ? 0 : epos[t] >= sub_hi ? 32 : epos[t] - sub_lo;
-        const u32 k_hi = lim[t] >= sub_hi ? 32 : lim[t] <= sub_lo ? 0 : lim[t] - sub_lo;
-        u32 own = k_lo >= 32 ? 0 : 0xFFFFFFFFu << k_lo;
-        if (k_hi < 32) own &= (1u << k_hi) - 1;
-        const u32 charmask = own & ~lenmask;
-        const u32 mine = __popc(charmask) | (__popc(smask) << 16);
-        u32 incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const u32 x = __shfl_up(incl, d);
-            if (lane >= (u32)d) incl += x;
-        }
-        n_chars[t] = __shfl(incl, 63) & 0xFFFF;
-        const u32 pc = (incl - mine) & 0xFFFF, ps = (incl - mine) >> 16;
         {
             int32_t* const offs = (int32_t*)R.out;
             const u32 cap = R.width;  // entries of the chunk's offsets array in front of the closing one
-            const u32 sbase = (u32)R.run_base + sub_lo;
-            u32 m = smask, rank = excl[t] + ps;
+            const u32 sbase = (u32)R.run_base + tb[t] + lane * CH_SUB;
+            u32 m = S[t], rank = excl + ps[t];
             while (m) {
                 const u32 k = __ffs(m) - 1;
                 m &= m - 1;
@@ -1417,37 +1491,22 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
                 rank++;
             }
         }
-        cdst[t] = R.out2 + (q0 - 4ull * excl[t]);
-        pad[t] = (u32)((uintptr_t)cdst[t] & 15);
-        u8* const stage = (u8*)s_buf[tu];  // every read of the tile image is over
-#pragma unroll
-        for (int k = 0; k < (int)CH_SUB; k++)
-            if ((charmask >> k) & 1) stage[pad[t] + pc + __popc(charmask & ((1u << k) - 1))] = (u8)(w[t][k >> 2] >> (8 * (k & 3)));
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (u32 t = 0; t < NT; t++) {
-        if (!emit[t]) continue;
-        const u32 tu = wv * NT + t;
-        const u8* const stage = (const u8*)s_buf[tu];
-        u8* const cd = cdst[t];
-        const u32 pd0 = pad[t], n_stg = pd0 + n_chars[t];
+        u8* const cd = R.out2 + (q0 - 4ull * excl);
+        const u32 pd0 = (u32)((uintptr_t)cd & 15), shift = pd0 - a3[t];  // pd0 % 4 == a3: the image is `shift` bytes (0, 4, 8, 12) ahead
+        const u8* const stage = (const u8*)s_buf[tu] - shift;              // stage[pd0 + i] = byte i of the tile's chars
+        const u32 n_stg = pd0 + n_chars[t];
+        // aligned 16-byte stores between the first and the last 16-byte boundary; the up to 15 bytes on either side go one per lane
         const u32 head_end = ((pd0 + 15) & ~15u) < n_stg ? ((pd0 + 15) & ~15u) : n_stg;
         const u32 tail_lo = (n_stg & ~15u) > head_end ? (n_stg & ~15u) : head_end;
-        for (u32 c0 = head_end + lane * 16; c0 < tail_lo; c0 += 64 * 16) *(u32x4*)(cd - pd0 + c0) = *(const u32x4*)(stage + c0);
+        for (u32 c0 = head_end + lane * 16; c0 < tail_lo; c0 += 64 * 16) {
+            const u32* const sp = (const u32*)(stage + c0);  // 4-byte aligned
+            *(u32x4*)(cd - pd0 + c0) = u32x4{sp[0], sp[1], sp[2], sp[3]};
+        }
         if (lane < 16) { if (pd0 + lane < head_end) cd[lane] = stage[pd0 + lane]; }
         else if (lane < 32) { const u32 b = tail_lo + lane - 16; if (b < n_stg) cd[b - pd0] = stage[b]; }
-        // the last string of the tile may run past the tile: its remaining chars follow directly
-        const u32 lq = lastq[t], ln = ext[t];
-        if (ln != ERR_POS && ln != SF_PASS && ln > lim[t]) {
-            const u32 s_lo = lq + 4 > lim[t] ? lq + 4 : lim[t];
-            const u8* sp = rsrc + s_lo;
-            u8* dp = cd + n_chars[t];
-            const u32 n = ln - s_lo, n16 = n & ~15u;
-            for (u32 c0 = lane * 16; c0 < n16; c0 += 64 * 16) *(u32x4_u*)(dp + c0) = *(const u32x4_u*)(sp + c0);
-            if (lane < 16 && n16 + lane < n) dp[n16 + lane] = sp[n16 + lane];
-        }
     }
+    SF_STAMP(9);
+#undef SF_STAMP
 }
 
 // k_str_totals — after k_str_fused, one thread per string page: the page's string count and its place in the chunk's
@@ -2736,7 +2795,7 @@ static hipError_t launch_chain_t(hipStream_t st, const u8* src, const ChainArgs&
         }
     } else if (a.n_tiles) {
         if constexpr (KIND == KIND_STRINGS)
-            hipLaunchKernelGGL(k_str_mark, dim3((a.n_tiles + STR_MG - 1) / STR_MG), dim3(CH_THREADS), 0, st, src, a.regions,
+            hipLaunchKernelGGL(k_str_mark, dim3(gate_any && (a.n_tiles + STR_MG - 1) / STR_MG > 8192 ? 8192 : (a.n_tiles + STR_MG - 1) / STR_MG), dim3(CH_THREADS), 0, st, src, a.regions,
                                a.tile_prefix, a.n_regions, a.n_tiles, a.tile_entry, (const u32x4*)a.str_cp, page_dyn, a.tile_region, status, gate_any);
         else
             hipLaunchKernelGGL((k_chain<KIND, true, CHAIN_NT_MARK>), dim3(a.n_tiles), dim3(CHAIN_NT_MARK), 0, st, src, a.regions, a.tile_prefix,
@@ -2756,8 +2815,8 @@ hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs
 hipError_t launch_str_fused(hipStream_t st, const u8* src, const ChainArgs& a, PageDyn* str_pd) {
     if (a.n_regions == 0) return hipSuccess;
     if (a.n_units) {
-        hipLaunchKernelGGL(k_str_fused, dim3(a.n_units), dim3(SF_THREADS), 0, st, src, a.regions, a.unit_order, a.unit_region,
-                           a.str_stat, a.str_failed, a.str_any);
+        hipLaunchKernelGGL(k_str_fused, dim3(a.n_units), dim3(SF_THREADS), 0, st, src, a.regions, a.units,
+                           a.str_stat, a.str_failed, a.str_any, a.str_stamps);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_str_totals, dim3((a.n_regions + 63) / 64), dim3(64), 0, st, a.regions, a.n_regions, a.str_stat,
