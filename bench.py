@@ -308,8 +308,24 @@ def timed(ld, steps, warmup, before_step=None, barrier=None):
     return elapsed, float(np.mean(tot_ms)), float(np.mean(cp_ms))
 
 
+def spawn_ranks(args):
+    """`--gpus N` without a launcher around it: start N ranks (one per GPU) through torch.distributed.run as a child
+    process and pass its output and exit code on.  This process never touches a GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -349,9 +365,39 @@ def main():
 
     rows_local = torch.tensor([ld.pf.num_rows], dtype=torch.int64, device=coll_dev)
     rows_all = torch.zeros(world, dtype=torch.int64, device=coll_dev)
+    # The exchange of the per-shard row counts.  Over RCCL it is the decoder library's own gather (pqd_rccl_*: its
+    # communicator owns stream and buffers); rank 0's id travels through torch.distributed once.  Over gloo (several ranks
+    # on one GPU, which RCCL does not allow) it is torch.distributed's all_gather.
+    from parquet_amd import _native as N
+    comm = None
+    collective = "none"
+    if use_dist and args.dist_backend == "nccl":
+        ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            raw = (C.c_char * 128)()
+            rc = N.decode.pqd_rccl_unique_id(raw)
+            if rc != 0:
+                raise SystemExit("pqd_rccl_unique_id failed: %d" % rc)
+            ident.copy_(torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8))
+        dist.broadcast(ident, 0)
+        raw = (C.c_char * 128).from_buffer_copy(bytes(ident.cpu().numpy().tobytes()))
+        comm = C.c_void_p()
+        rc = N.decode.pqd_rccl_comm_create(local_rank, rank, world, raw, C.byref(comm))
+        if rc != 0:
+            raise SystemExit("pqd_rccl_comm_create failed: %d" % rc)  # no silent fallback
+        collective = "rccl (pqd_rccl_gather_rows: ncclAllGather of one int64 per rank)"
+    elif use_dist:
+        collective = "gloo (torch.distributed all_gather)"
+    all_rows_buf = (C.c_int64 * world)()
+    row_off = C.c_int64(0)
 
     def gather_rows():  # per-shard row counts → global row offsets
-        dist.all_gather_into_tensor(rows_all, rows_local)
+        if comm is not None:
+            rc = N.decode.pqd_rccl_gather_rows(comm, ld.pf.num_rows, all_rows_buf, C.byref(row_off))
+            if rc != 0:
+                raise SystemExit("pqd_rccl_gather_rows failed: %d" % rc)
+        else:
+            dist.all_gather_into_tensor(rows_all, rows_local)
 
     steps = args.steps
     elapsed, step_ms, cp_ms = timed(ld, steps, args.warmup, gather_rows if use_dist else None, dist.barrier if use_dist else None)
@@ -405,7 +451,7 @@ def main():
                 "algorithmic_bytes_per_step_per_gpu": alg,
                 "sharding": "row groups per rank, no data-path collective; all_gather of row counts per step" if world > 1 else "single GPU",
             },
-            "collective": {"backend": ("rccl (torch nccl)" if args.dist_backend == "nccl" else "gloo") if use_dist else "none", "world": world},
+            "collective": {"backend": collective, "world": world, "rows_per_rank": list(all_rows_buf) if comm is not None else rows_all.tolist()},
             # whole step: algorithmic bytes of one plan run / its device time (HIP events on the decoder's stream, average
             # over the timed steps); a step is a fixed sequence of launches on three streams, so there is no single launch
             "roofline": {
@@ -452,6 +498,8 @@ def main():
             res["per_workload"] = extras
         print(json.dumps(res), flush=True)
     ctx.close()
+    if comm is not None:
+        N.decode.pqd_rccl_comm_destroy(comm)
     if use_dist:
         dist.destroy_process_group()
 

@@ -174,10 +174,14 @@ int64_t pqd_plan_string_fallbacks(pqd_plan* plan);
 int64_t pqd_plan_debug_stamps(pqd_plan* plan, void* dst, size_t cap);
 
 /* Convenience: host buffer in, results on device; = copy_to_device + plan_create + run + sync.
- * The plan owns the device copy of `src`. */
+ * Only the byte range that the described pages cover (first payload byte to last, the page headers between them
+ * included) is copied to the device, so decoding a file row group by row group, as readRowGroup does
+ * (template.go:320-351), moves every byte of it once.  The plan owns the device copy. */
 int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                const pqd_page_desc* pages, size_t n_pages,
                const void* src_host, size_t src_len, pqd_plan** out);
+/* Bytes pqd_decode copied from host to device for this plan (0 for a plan made by pqd_plan_create). */
+int64_t pqd_plan_h2d_bytes(pqd_plan* plan);
 
 /* ---- standalone level decode: rle.Read (internal/rle/rle.go:159-195) for one block ----------
  * `block` = int32 LE length + runs, in host memory.  width 0..32; out_elem_size 1 (width <= 8),
@@ -338,12 +342,13 @@ const char* pqd_multi_last_error(const pqd_multi* m);
 
 /* One process per GPU: the row counts go through RCCL (ncclAllGather of one int64 per rank, xGMI inside a node).
  * librccl is loaded on first use (PQD_E_UNSUPPORTED when it is absent).  Rank 0 makes the 128-byte id and hands it
- * to the other ranks by whatever means the host program has; `comm` is an ncclComm_t. */
+ * to the other ranks by whatever means the host program has.  A communicator owns its RCCL communicator, a stream and
+ * 8 (world + 1) bytes of device and of pinned host memory, so that a gather allocates and creates nothing. */
 int pqd_rccl_unique_id(void* id128);
 int pqd_rccl_comm_create(int device, int rank, int world, const void* id128, void** comm);
 void pqd_rccl_comm_destroy(void* comm);
-/* all_rows: host array of `world` entries; *row_offset = rows of the ranks in front of this one. */
-int pqd_rccl_gather_rows(int device, void* comm, int rank, int world, int64_t local_rows, int64_t* all_rows, int64_t* row_offset);
+/* all_rows: host array of `world` entries; *row_offset = rows of the ranks in front of this one.  Waits for the result. */
+int pqd_rccl_gather_rows(void* comm, int64_t local_rows, int64_t* all_rows, int64_t* row_offset);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,7 @@ DECODE_SYMBOLS = {
     "pqd_plan_fetch": (C.c_int64, [_P, C.c_size_t, C.c_int, _P, C.c_size_t]),
     "pqd_plan_scatter": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t]),
     "pqd_plan_string_fallbacks": (C.c_int64, [_P]),
+    "pqd_plan_h2d_bytes": (C.c_int64, [_P]),
     "pqd_plan_debug_stamps": (C.c_int64, [_P, _P, C.c_size_t]),
     "pqd_decode": (C.c_int, [_P, C.POINTER(ChunkDesc), C.c_size_t, C.POINTER(PageDesc), C.c_size_t,
                              _P, C.c_size_t, C.POINTER(_P)]),
@@ -120,7 +121,7 @@ DECODE_SYMBOLS = {
     "pqd_rccl_unique_id": (C.c_int, [_P]),
     "pqd_rccl_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),
     "pqd_rccl_comm_destroy": (None, [_P]),
-    "pqd_rccl_gather_rows": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pqd_rccl_gather_rows": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
 SYNTH_SYMBOLS = {

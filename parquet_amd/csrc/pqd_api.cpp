@@ -53,6 +53,7 @@ struct pqd_plan {
     pqd_ctx* ctx = nullptr;
     size_t src_len = 0;
     u8* owned_src = nullptr;       // device copy made by pqd_decode
+    int64_t h2d_bytes = 0;         // bytes pqd_decode copied to the device for this plan
     const u8* last_src = nullptr;
 
     // host copies of the tables
@@ -940,6 +941,8 @@ int pqd_plan_scatter(pqd_plan* pl, size_t c, void* dst_device, size_t dst_bytes)
     return PQD_OK;
 }
 
+int64_t pqd_plan_h2d_bytes(pqd_plan* pl) { return pl ? pl->h2d_bytes : PQD_E_ARG; }
+
 int64_t pqd_plan_string_fallbacks(pqd_plan* pl) {
     if (!pl || !pl->synced) return PQD_E_ARG;
     int64_t n = 0;
@@ -983,13 +986,25 @@ int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks, cons
                 return fail(ctx, PQD_E_CORRUPT, "page payload outside the source buffer");
         }
     }
+    // Only the bytes that the described pages cover go to the device (readRowGroup consumes its own row group's bytes
+    // and nothing else, template.go:320-351): [lo, hi) = from the first payload byte to the last, page headers between
+    // them included.  Everything below works on offsets relative to lo.
+    uint64_t lo = src_len, hi = 0;
+    for (size_t c = 0; c < n_chunks; c++)
+        for (int k = 0; k < chunks[c].n_pages; k++) {
+            const pqd_page_desc& pd = pages[(size_t)chunks[c].first_page + k];
+            lo = std::min<uint64_t>(lo, (uint64_t)pd.src_off);
+            hi = std::max<uint64_t>(hi, (uint64_t)pd.src_off + (uint64_t)pd.payload_len);
+        }
+    if (hi < lo) lo = hi = 0;  // no pages
+    const u8* const host = (const u8*)src_host + lo;
+    const size_t span = (size_t)(hi - lo);
+    for (pqd_page_desc& pd : pv) pd.src_off -= (int64_t)lo;
     std::vector<pqd_snappy_block> blocks;
     std::vector<size_t> block_page;
     for (size_t c = 0; c < n_chunks; c++) {
         if (cv[c].codec == 0) continue;
         if (cv[c].codec != 1) return fail(ctx, PQD_E_UNSUPPORTED, "codec other than UNCOMPRESSED and SNAPPY");
-        if (cv[c].first_page < 0 || cv[c].n_pages < 0 || (size_t)cv[c].first_page + (size_t)cv[c].n_pages > n_pages)
-            return fail(ctx, PQD_E_ARG, "chunk page range out of bounds");
         for (int k = 0; k < cv[c].n_pages; k++) {
             const size_t pi = (size_t)cv[c].first_page + k;
             pqd_snappy_block b;
@@ -1001,10 +1016,10 @@ int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks, cons
         }
         cv[c].codec = 0;
     }
-    const size_t file_area = align_up(src_len + 64, 256);
+    const size_t file_area = align_up(span + 64, 256);
     size_t total = file_area;
     if (!blocks.empty()) {
-        int rc = pqd_snappy_sizes(src_host, src_len, blocks.data(), blocks.size());
+        int rc = pqd_snappy_sizes(host, span, blocks.data(), blocks.size());
         if (rc) return fail(ctx, rc, "bad snappy preamble or page outside the file");
         for (size_t i = 0; i < blocks.size(); i++) {
             if (blocks[i].decoded_len > 0x7fffffff) return fail(ctx, PQD_E_UNSUPPORTED, "snappy page of 2 GiB or more");
@@ -1017,9 +1032,9 @@ int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks, cons
     }
     u8* dsrc = (u8*)pqd_device_alloc(ctx, total);
     if (!dsrc) return fail(ctx, PQD_E_NOMEM, "device allocation for the source failed");
-    int rc = pqd_copy_to_device(ctx, dsrc, src_host, src_len);
+    int rc = span ? pqd_copy_to_device(ctx, dsrc, host, span) : PQD_OK;
     if (!rc && !blocks.empty()) {
-        rc = pqd_snappy_decode(ctx, blocks.data(), blocks.size(), dsrc, src_len, dsrc + file_area, total - file_area);
+        rc = pqd_snappy_decode(ctx, blocks.data(), blocks.size(), dsrc, span, dsrc + file_area, total - file_area);
         // the level block sizes of decoded pages can only be read on the device
         if (!rc) rc = pqd_level_block_sizes(ctx, cv.data(), n_chunks, pv.data(), n_pages, dsrc, total);
         if (!rc)
@@ -1031,11 +1046,13 @@ int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks, cons
                     }
     }
     pqd_plan* pl = nullptr;
-    if (!rc) rc = pqd_plan_create(ctx, cv.data(), n_chunks, pv.data(), n_pages, src_host, total, &pl);
+    // the planner reads level block lengths of uncompressed pages from the host bytes: the same range, the same offsets
+    if (!rc) rc = pqd_plan_create(ctx, cv.data(), n_chunks, pv.data(), n_pages, host, total, &pl);
     if (rc) {
         pqd_device_free(ctx, dsrc);
         return rc;
     }
+    pl->h2d_bytes = (int64_t)span;
     pl->owned_src = dsrc;
     if ((rc = pqd_plan_run(pl, pl->owned_src))) {
         pqd_plan_destroy(pl);

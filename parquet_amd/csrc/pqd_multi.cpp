@@ -213,40 +213,63 @@ int pqd_rccl_unique_id(void* id128) {
     return g_rccl.GetUniqueId(id128) == 0 ? PQD_OK : PQD_E_HIP;
 }
 
+// A communicator owns what a gather needs, so that the gather itself allocates and creates nothing: the RCCL
+// communicator, a stream, 8 (world + 1) bytes of device memory ([0] = this rank's count, [1 .. world] = everyone's)
+// and the same in pinned host memory.
+struct pqd_rccl_comm {
+    void* nccl = nullptr;
+    int device = 0, rank = 0, world = 1;
+    hipStream_t stream = nullptr;
+    int64_t* d = nullptr;
+    int64_t* h = nullptr;
+};
+
+void pqd_rccl_comm_destroy(void* comm_) {
+    pqd_rccl_comm* c = (pqd_rccl_comm*)comm_;
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    if (c->nccl && rccl_load()) (void)g_rccl.CommDestroy(c->nccl);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->d) (void)hipFree(c->d);
+    if (c->h) (void)hipHostFree(c->h);
+    delete c;
+}
+
 int pqd_rccl_comm_create(int device, int rank, int world, const void* id128, void** comm) {
     if (!id128 || !comm || rank < 0 || world <= 0 || rank >= world) return PQD_E_ARG;
     if (!rccl_load()) return PQD_E_UNSUPPORTED;
     if (hipSetDevice(device) != hipSuccess) return PQD_E_HIP;
+    pqd_rccl_comm* c = new pqd_rccl_comm();
+    c->device = device; c->rank = rank; c->world = world;
+    const size_t bytes = ((size_t)world + 1) * 8;
     Id128 id;
     memcpy(id.b, id128, sizeof id.b);
-    return g_rccl.CommInitRank(comm, world, id, rank) == 0 ? PQD_OK : PQD_E_HIP;
-}
-
-void pqd_rccl_comm_destroy(void* comm) {
-    if (comm && rccl_load()) (void)g_rccl.CommDestroy(comm);
-}
-
-int pqd_rccl_gather_rows(int device, void* comm, int rank, int world, int64_t local_rows, int64_t* all_rows, int64_t* row_offset) {
-    if (!comm || !all_rows || rank < 0 || world <= 0 || rank >= world) return PQD_E_ARG;
-    if (!rccl_load()) return PQD_E_UNSUPPORTED;
-    if (hipSetDevice(device) != hipSuccess) return PQD_E_HIP;
-    int64_t* d = nullptr;  // [0] = mine, [1 .. world] = everyone's
-    if (hipMalloc((void**)&d, ((size_t)world + 1) * 8) != hipSuccess) return PQD_E_NOMEM;
-    int rc = PQD_OK;
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = PQD_E_HIP;
-    if (rc == PQD_OK && hipMemcpyAsync(d, &local_rows, 8, hipMemcpyHostToDevice, st) != hipSuccess) rc = PQD_E_HIP;
-    if (rc == PQD_OK && g_rccl.AllGather(d, d + 1, 1, /* ncclInt64 */ 4, comm, st) != 0) rc = PQD_E_HIP;
-    if (rc == PQD_OK && hipMemcpyAsync(all_rows, d + 1, (size_t)world * 8, hipMemcpyDeviceToHost, st) != hipSuccess) rc = PQD_E_HIP;
-    if (rc == PQD_OK && hipStreamSynchronize(st) != hipSuccess) rc = PQD_E_HIP;
-    if (st) (void)hipStreamDestroy(st);
-    (void)hipFree(d);
-    if (rc == PQD_OK && row_offset) {
-        int64_t o = 0;
-        for (int r = 0; r < rank; r++) o += all_rows[r];
-        *row_offset = o;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d, bytes) != hipSuccess ||
+        hipHostMalloc((void**)&c->h, bytes, hipHostMallocDefault) != hipSuccess || g_rccl.CommInitRank(&c->nccl, world, id, rank) != 0) {
+        pqd_rccl_comm_destroy(c);
+        return PQD_E_HIP;
     }
-    return rc;
+    *comm = c;
+    return PQD_OK;
+}
+
+int pqd_rccl_gather_rows(void* comm_, int64_t local_rows, int64_t* all_rows, int64_t* row_offset) {
+    pqd_rccl_comm* c = (pqd_rccl_comm*)comm_;
+    if (!c || !all_rows) return PQD_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return PQD_E_HIP;
+    c->h[0] = local_rows;
+    if (hipMemcpyAsync(c->d, c->h, 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return PQD_E_HIP;
+    if (g_rccl.AllGather(c->d, c->d + 1, 1, /* ncclInt64 */ 4, c->nccl, c->stream) != 0) return PQD_E_HIP;
+    if (hipMemcpyAsync(c->h + 1, c->d + 1, (size_t)c->world * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return PQD_E_HIP;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return PQD_E_HIP;
+    int64_t o = 0;
+    for (int r = 0; r < c->world; r++) {
+        all_rows[r] = c->h[1 + r];
+        if (r < c->rank) o += c->h[1 + r];
+    }
+    if (row_offset) *row_offset = o;
+    return PQD_OK;
 }
 
 }  // extern "C"
