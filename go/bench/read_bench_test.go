@@ -16,7 +16,7 @@ import (
 )
 
 func load(b *testing.B) []byte {
-	path := os.Getenv("PQ_BENCH_FILE") // an UNCOMPRESSED file written by the reference writer or tools/make_bench_file.py
+	path := os.Getenv("PQ_BENCH_FILE") // an UNCOMPRESSED Person file written by the reference writer or by `python tools/make_bench_file.py out.parquet`
 	buf, err := os.ReadFile(path)
 	if err != nil {
 		b.Skipf("PQ_BENCH_FILE not readable: %v", err)

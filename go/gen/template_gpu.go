@@ -2,7 +2,7 @@
 // Everything else of the generated file (writer, stats, Scan, Next, Levels, the Field constructors) stays as
 // cmd/parquetgen/gen/template*.go emit it today, so NewParquetReader / Next / Scan keep their signatures.
 //
-// To apply: add `"github.com/parsyl/parquet/gpu"` to the generated imports, replace the `readRowGroup`
+// To apply: add `"github.com/parsyl/parquet/gpu"` and `sch "github.com/parsyl/parquet/schema"` to the generated imports, replace the `readRowGroup`
 // definition of template.go:320-351 with gpuReadRowGroupTpl, append gpuReaderSupportTpl to `tpl`, and append
 // the matching Adopt template to each of the six field templates next to the Read method it stands in for
 // (template_required.go:25-35, template_optional.go:42-52, template_string.go:41-60,
@@ -56,8 +56,12 @@ func (p *ParquetReader) readRowGroup() error {
 		if err != nil {
 			return fmt.Errorf("unable to read field %s, err: %s", f.Name(), err)
 		}
+		codec, err := gpuCodec(pg.Codec)
+		if err != nil {
+			return fmt.Errorf("unable to read field %s, err: %s", f.Name(), err)
+		}
 		chunks = append(chunks, gpu.Chunk{PhysType: gf.PhysicalType(), MaxDef: d, MaxRep: r,
-			FirstPage: int32(first), NPages: int32(len(pages) - first), NumValues: int64(pg.N), Codec: gpuCodec(pg.Codec)})
+			FirstPage: int32(first), NPages: int32(len(pages) - first), NumValues: int64(pg.N), Codec: codec})
 		order = append(order, gf)
 		p.pages[name] = p.pages[name][1:]
 	}
@@ -143,11 +147,18 @@ func (p *ParquetReader) Close() {
 	}
 }
 
-func gpuCodec(c string) int32 {
-	if c == "SNAPPY" {
-		return 1
+// gpuCodec maps parquet.Page.Codec (sch.CompressionCodec, an int64 enum: parquet.go:33, schema/parquet.go:356-360)
+// to the library's codec number.  What the device does not decode is an error, in the words of pageData's default
+// arm (fields.go:397-398): GZIP pages are not silently read as uncompressed bytes.
+func gpuCodec(c sch.CompressionCodec) (int32, error) {
+	switch c {
+	case sch.CompressionCodec_UNCOMPRESSED:
+		return 0, nil
+	case sch.CompressionCodec_SNAPPY:
+		return 1, nil
+	default:
+		return 0, fmt.Errorf("unsupported column chunk codec: %s", c)
 	}
-	return 0 // pageData's default arm (fields.go:392-396)
 }
 
 // walkPageHeaders reads the thrift page headers of one column chunk and skips the payloads, appending one

@@ -148,6 +148,9 @@ func (c *Ctx) Decode(file *HostBuf, chunks []Chunk, pages []Page) (*Result, erro
 type Info struct{ NLevels, NValues, ValueBytes, CharsBytes, NRows, NPages int64 }
 
 func (r *Result) Info(chunk int) (Info, error) {
+	if r.plan == nil {
+		return Info{}, fmt.Errorf("no decoded row group (empty batch or closed result)")
+	}
 	var ci C.pqd_chunk_info
 	if rc := C.pqd_plan_chunk_info(r.plan, C.size_t(chunk), &ci); rc != 0 {
 		return Info{}, fmt.Errorf("pqd_plan_chunk_info: status %d", int(rc))
@@ -157,6 +160,9 @@ func (r *Result) Info(chunk int) (Info, error) {
 
 // Fetch copies one decoded array of one chunk into dst and returns the bytes copied.
 func (r *Result) Fetch(chunk int, which Output, dst []byte) (int, error) {
+	if r.plan == nil {
+		return 0, fmt.Errorf("no decoded row group (empty batch or closed result)")
+	}
 	if len(dst) == 0 {
 		return 0, nil
 	}
@@ -207,11 +213,18 @@ func (r *Result) Strings(chunk int) ([]string, error) {
 	if err != nil {
 		return nil, err
 	}
+	if int64(len(ob)) < 4*(ci.NValues+1) {
+		return nil, fmt.Errorf("string chunk %d: %d offset bytes for %d values", chunk, len(ob), ci.NValues)
+	}
 	all := string(chars) // one copy; the values below share it
 	out := make([]string, ci.NValues)
 	offs := unsafe.Slice((*int32)(unsafe.Pointer(&ob[0])), ci.NValues+1)
 	for i := range out {
-		out[i] = all[offs[i]:offs[i+1]]
+		lo, hi := int64(offs[i]), int64(offs[i+1])
+		if lo < 0 || hi < lo || hi > int64(len(all)) {
+			return nil, fmt.Errorf("string chunk %d: offsets of value %d out of order or outside the %d chars", chunk, i, len(all))
+		}
+		out[i] = all[lo:hi]
 	}
 	return out, nil
 }
@@ -221,6 +234,9 @@ func (r *Result) Strings(chunk int) ([]string, error) {
 // NLevels+1 slot offsets into OutChars (a null has length 0).  The dense Values plus Defs stay what Scan consumes
 // (performance/parquet.go:104-113); this is for callers that want one entry per row.
 func (r *Result) Scattered(chunk int, slotBytes int, strings bool) ([]byte, error) {
+	if r.plan == nil {
+		return nil, fmt.Errorf("no decoded row group (empty batch or closed result)")
+	}
 	ci, err := r.Info(chunk)
 	if err != nil {
 		return nil, err

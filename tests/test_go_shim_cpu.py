@@ -3,6 +3,8 @@ symbol, constant and struct field the cgo file uses must exist in include/pqdeco
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -42,3 +44,88 @@ def test_templates_name_only_shim_functions_that_exist():
         assert name in exported, "template_gpu.go uses gpu.%s, which go/gpu/pqdecode.go does not define" % name
     for m in set(re.findall(r"\bres\.(\w+)\(", tpl)):
         assert re.search(r"func \(r \*Result\) %s\(" % m, go), m
+
+
+# ---- the templates against the reference's own declarations (skipped where the reference is not mounted)
+REF = "/root/reference"
+
+
+def _go_struct_fields(src, name):
+    """{field: type} of `type <name> struct { ... }` in Go source text."""
+    m = re.search(r"type %s struct \{(.*?)\n\}" % re.escape(name), src, re.S)
+    assert m, name
+    out = {}
+    for line in m.group(1).splitlines():
+        line = line.split("//")[0].strip()
+        if not line:
+            continue
+        parts = line.split()
+        if len(parts) >= 2:
+            for f in parts[0].split(","):
+                out[f.strip()] = parts[1]
+    return out
+
+
+def _go_func_params(src, name):
+    """Parameter types of `func name(...)` / `func (r T) name(...)` in Go source text, in order."""
+    m = re.search(r"func (?:\([^)]*\) )?%s\(([^)]*)\)" % re.escape(name), src)
+    assert m, name
+    types = []
+    pending = 0
+    for part in [p.strip() for p in m.group(1).split(",") if p.strip()]:
+        bits = part.split()
+        if len(bits) == 1:
+            pending += 1  # `a, b T`: the type follows with a later name
+        else:
+            types += [bits[-1]] * (pending + 1)
+            pending = 0
+    return types
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference not mounted")
+def test_templates_use_the_reference_types_as_declared():
+    tpl = _read("go", "gen", "template_gpu.go")
+    ref_parquet = open(os.path.join(REF, "parquet.go")).read()
+    ref_schema = open(os.path.join(REF, "schema", "parquet.go")).read()
+    ref_tpl = open(os.path.join(REF, "cmd", "parquetgen", "gen", "template.go")).read()
+    page = _go_struct_fields(ref_parquet, "Page")
+    # every pg.X the templates read is a field of parquet.Page
+    used = set(re.findall(r"\bpg\.(\w+)", tpl))
+    assert used and used <= set(page), (used, page)
+    # pg.Codec goes to gpuCodec, whose parameter is the field's declared type (an int64 enum, not a string)
+    assert page["Codec"] == "sch.CompressionCodec"
+    assert re.search(r"type CompressionCodec int64", ref_schema)
+    assert _go_func_params(tpl, "gpuCodec") == [page["Codec"]]
+    assert re.search(r"func gpuCodec\([^)]*\) \(int32, error\)", tpl)
+    for const in re.findall(r"sch\.(CompressionCodec_\w+)", tpl):
+        assert re.search(r"\b%s CompressionCodec = \d" % const, ref_schema), const
+    assert '"unsupported column chunk codec: %s"' in tpl  # the words of fields.go's default arm
+    assert 'unsupported column chunk codec: %s' in open(os.path.join(REF, "fields.go")).read()
+    # pg.N and pg.Size are compared with an int counter in walkPageHeaders
+    assert page["N"] == "int" and page["Size"] == "int"
+    assert re.search(r"var nRead int\b", tpl)
+    # ph.X: fields of the thrift PageHeader / DataPageHeader the walk reads
+    ph = _go_struct_fields(ref_schema, "PageHeader")
+    dph = _go_struct_fields(ref_schema, "DataPageHeader")
+    for f in set(re.findall(r"\bph\.(\w+)", tpl)):
+        assert f in ph, f
+    for f in set(re.findall(r"\bph\.DataPageHeader\.(\w+)", tpl)):
+        assert f in dph, f
+    assert ph["CompressedPageSize"] == "int32" and dph["NumValues"] == "int32"
+    # parquet.X: functions and types of the reference package that the templates call
+    for name in set(re.findall(r"\bparquet\.([A-Z]\w*)", tpl)):
+        assert re.search(r"^(?:func|type) (?:\([^)]*\) )?%s\b" % name, ref_parquet, re.M), name
+    assert _go_func_params(ref_parquet, "PageHeader") == ["io.Reader"]
+    # p.X: fields of the generated ParquetReader that readRowGroup touches (the GPU ones are added by the support template)
+    reader = _go_struct_fields(ref_tpl, "ParquetReader")
+    added = {"device", "gpu", "file", "gpuInit"}
+    for f in set(re.findall(r"\bp\.(\w+)", tpl)) - added:
+        assert f in reader or re.search(r"func \(p \*ParquetReader\) %s\(" % f, ref_tpl + tpl), f
+    # the struct the row group columns come from
+    assert re.search(r"func \(r RowGroup\) Columns\(\)", ref_parquet) or re.search(r"Columns\(\)", ref_parquet)
+
+
+def test_bench_file_tool_named_by_the_go_bench_exists():
+    go = _read("go", "bench", "read_bench_test.go")
+    for tool in re.findall(r"tools/(\w+\.py)", go):
+        assert os.path.exists(os.path.join(ROOT, "tools", tool)), tool
