@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--pages", type=int, default=None, help="pages per column chunk (default 1 for mixed, 64 for flat, 8 otherwise)")
     ap.add_argument("--row-groups", type=int, default=None, help="row groups per GPU (default 96 for mixed, 4 for flat, 2 otherwise)")
     ap.add_argument("--rows-per-page", type=int, default=1_000_000)
-    ap.add_argument("--workload", default="mixed", choices=["mixed", "flat", "optional", "optint", "optstr", "nested", "bools"])
+    ap.add_argument("--workload", default="mixed", choices=["mixed", "flat", "optional", "optint", "optstr", "nested", "bools", "wide"])
     ap.add_argument("--no-extras", action="store_true", help="skip the per-workload lines measured beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="per CPU baseline leg (one thread, all cores)")
@@ -95,8 +95,67 @@ def _person_cols(N, Column):
             Column("friends.id", N.INT32, [2, 0]), Column("friends.age", N.INT32, [2, 1])]
 
 
+def _wide_cols(N, Column):
+    """The rest of the type list, and the level widths the Person columns do not reach: bools, float32, uint32 / uint64
+    (physical INT32 / INT64 with converted types UINT_32 / UINT_64, template.go:464-481), the Dremel Document
+    (cmd/parquetgen/dremel/testcases/doc/doc.go:5-24: definition levels up to 3, repetition levels up to 2: widths
+    2 / 2) and a five-deep chain of optional and repeated groups (definition levels up to 5: width 3)."""
+    from parquet_amd.writer import UINT_32, UINT_64
+    return [Column("b", N.BOOLEAN, [0]), Column("ob", N.BOOLEAN, [1]), Column("f32", N.FLOAT, [0]), Column("of32", N.FLOAT, [1]),
+            Column("u32", N.INT32, [0], UINT_32), Column("ou64", N.INT64, [1], UINT_64),
+            Column("links.backward", N.INT64, [1, 2]), Column("names.languages.country", N.BYTE_ARRAY, [2, 2, 1]),
+            Column("a.b.c.d.e", N.INT32, [1, 2, 1, 2, 1])]
+
+
+def gen_nested_levels(types, n_rows, rng, p_null=0.25, max_count=3):
+    """Dremel levels of one leaf whose path has the given repetition types (0 required, 1 optional, 2 repeated), for
+    n_rows records: (defs, reps).  An optional group is absent with p_null, a repeated one has 0..max_count entries; the
+    record is cut off where a group is absent or empty (one level with the definition level reached), as the generated
+    read functions of the reference shred it (cmd/parquetgen/dremel/write_optional.go, write_repeated.go)."""
+    defs = np.zeros(n_rows, np.uint8)
+    reps = np.zeros(n_rows, np.uint8)
+    alive = np.ones(n_rows, bool)
+    r = 0
+    for t in types:
+        if t == 1:
+            gone = alive & (rng.random(defs.size) < p_null)
+            defs = defs + (alive & ~gone)
+            alive = alive & ~gone
+        elif t == 2:
+            r += 1
+            k = rng.integers(0, max_count + 1, defs.size)
+            k[~alive] = 1
+            alive = alive & (k > 0)
+            cnt = np.maximum(k, 1)
+            first = np.zeros(int(cnt.sum()), bool)
+            first[np.cumsum(cnt) - cnt] = True
+            defs, reps, alive = np.repeat(defs, cnt), np.repeat(reps, cnt), np.repeat(alive, cnt)
+            reps = np.where(first, reps, r).astype(np.uint8)
+            defs = defs + alive
+    return defs.astype(np.uint8), reps
+
+
 def _gen_page(N, name, rng, n):
     """One page of `n` rows of the named column: (values, defs, reps, offsets)."""
+    if name in ("f32", "of32", "u32", "ou64"):
+        mask = rng.random(n) >= 0.1 if name[0] == "o" else None
+        nv = int(mask.sum()) if mask is not None else n
+        v = {"f32": lambda: rng.random(nv, dtype=np.float32), "of32": lambda: rng.random(nv, dtype=np.float32),
+             "u32": lambda: rng.integers(0, 2**32, nv, dtype=np.uint64).astype(np.uint32),
+             "ou64": lambda: rng.integers(0, 2**63, nv, dtype=np.uint64) * np.uint64(2) + np.uint64(1)}[name]()
+        return v, (mask.astype(np.uint8) if mask is not None else None), None, None
+    if name in ("links.backward", "names.languages.country", "a.b.c.d.e"):
+        types = {"links.backward": [1, 2], "names.languages.country": [2, 2, 1], "a.b.c.d.e": [1, 2, 1, 2, 1]}[name]
+        defs, reps = gen_nested_levels(types, n, rng)
+        nv = int((defs == sum(1 for t in types if t)).sum())
+        if name == "links.backward":
+            return rng.integers(-2**63, 2**63 - 1, nv, dtype=np.int64), defs, reps, None
+        if name == "a.b.c.d.e":
+            return rng.integers(-2**31, 2**31 - 1, nv, dtype=np.int64).astype(np.int32), defs, reps, None
+        lens = rng.integers(2, 9, nv)  # country codes and names
+        offs = np.zeros(nv + 1, np.int32)
+        np.cumsum(lens, out=offs[1:])
+        return rng.integers(97, 123, int(offs[-1]), dtype=np.uint8), defs, reps, offs
     if name == "i32" or name == "being.id":
         return rng.integers(-2**31, 2**31 - 1, n, dtype=np.int64).astype(np.int32), None, None, None
     if name == "i64":
@@ -151,9 +210,9 @@ def build_file(workload, rg_ids, pages, rows_per_page):
     from parquet_amd.writer import Column, ParquetWriter
     cols = {"flat": _flat_cols(N, Column), "optional": _optional_cols(N, Column), "optint": _optional_cols(N, Column)[:1],
             "optstr": _optional_cols(N, Column)[1:], "bools": _bool_cols(N, Column),
-            "nested": [c for c in _person_cols(N, Column) if c.path != "username"],
+            "nested": [c for c in _person_cols(N, Column) if c.path != "username"], "wide": _wide_cols(N, Column),
             "mixed": _flat_cols(N, Column) + _optional_cols(N, Column) + _person_cols(N, Column)}[workload]
-    seed0 = {"flat": 1000, "optional": 2000, "optint": 2000, "optstr": 2000, "nested": 3000, "mixed": 5000, "bools": 6000}[workload]
+    seed0 = {"flat": 1000, "optional": 2000, "optint": 2000, "optstr": 2000, "nested": 3000, "mixed": 5000, "bools": 6000, "wide": 7000}[workload]
     w = ParquetWriter(cols, stats=True)
     w.reserve(len(rg_ids) * pages * rows_per_page * sum(30 if c.phys_type == N.BYTE_ARRAY else 10 for c in cols) + (1 << 20))
     ex = Expect()
@@ -241,10 +300,11 @@ def cpu_baseline(buf, pf, seconds, threads):
 
 
 DOMINANT = {"flat": "k_copy (PLAIN value gather)", "optint": "k_levels (single-pass level decode) beside k_copy",
-            "optional": "k_str_exits / k_str_mark (BYTE_ARRAY chain)", "optstr": "k_str_exits / k_str_mark (BYTE_ARRAY chain)",
+            "optional": "k_str_fused (BYTE_ARRAY pages in one pass)", "optstr": "k_str_fused (BYTE_ARRAY pages in one pass)",
             "nested": "k_levels (single-pass level decode) and k_rows (row offsets)",
             "bools": "k_bools (bit -> byte expansion) and k_levels",
-            "mixed": "k_copy, k_str_mark, k_str_exits and k_levels, side by side on three streams"}
+            "wide": "k_levels (widths 1-3), k_rows, k_copy, k_bools, k_str_fused",
+            "mixed": "k_str_fused, k_copy and k_levels, side by side on three streams"}
 DESCRIBE = {
     "mixed": "this GPU's share of configs[4]: configs[1]+[2]+[3] columns side by side (flat int32/int64/float64, optional int32 + string with "
              "10%% nulls, Person{Being,Username,Friends []Being}), %d rows/page, %d page(s)/chunk, %d row groups per GPU (uncompressed DATA_PAGE v1)",
@@ -253,9 +313,12 @@ DESCRIBE = {
     "nested": "configs[3]: Person{Being,Friends []Being} int32 leaves, %d rows/page, %d pages/chunk, %d row groups per GPU",
     "optint": "configs[2], int32 half: optional int32 column, 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
     "bools": "required + optional (10%% nulls) bool columns, %d rows/page, %d pages/chunk, %d row groups per GPU",
+    "wide": "the rest of the type list: required + optional bool, float32, uint32 / uint64, the Dremel Document columns links.backward and "
+            "names.languages.country (levels up to 3 / 2) and a five-deep chain a.b.c.d.e (definition levels up to 5, width 3), %d rows/page, "
+            "%d pages/chunk, %d row groups per GPU",
     "optstr": "configs[2], string half: optional string column (8-32 B), 10%% nulls, %d rows/page, %d pages/chunk, %d row groups per GPU",
 }
-DEFAULT_SHAPE = {"mixed": (1, 96), "flat": (64, 4), "optional": (8, 2), "optint": (8, 2), "optstr": (8, 2), "nested": (8, 2), "bools": (32, 2)}  # pages, row groups
+DEFAULT_SHAPE = {"mixed": (1, 96), "flat": (64, 4), "optional": (8, 2), "optint": (8, 2), "optstr": (8, 2), "nested": (8, 2), "bools": (32, 2), "wide": (2, 2)}  # pages, row groups
 
 
 class Loaded:
@@ -488,7 +551,7 @@ def main():
         if world == 1 and not args.no_extras and args.workload == "mixed":
             # the single-config workloads on smaller files, same run, same checks
             extras = {}
-            for wl, (pg, rgs) in (("flat", (32, 2)), ("optint", (32, 2)), ("optstr", (16, 2)), ("nested", (16, 2))):
+            for wl, (pg, rgs) in (("flat", (32, 2)), ("optint", (32, 2)), ("optstr", (16, 2)), ("nested", (16, 2)), ("wide", (2, 2))):
                 e = Loaded(ctx, wl, list(range(rgs)), pg, args.rows_per_page)
                 el, sm, _ = timed(e, 50, 3)
                 bi, bo, _ = e.plan.bytes()

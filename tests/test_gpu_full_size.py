@@ -25,8 +25,8 @@ def ctx():
     c.close()
 
 
-def _decode_and_verify(ctx, workload, oracle_columns):
-    buf, expect = bench.build_file(workload, [0], 2, 1_000_000)
+def _decode_and_verify(ctx, workload, oracle_columns, pages=2):
+    buf, expect = bench.build_file(workload, [0], pages, 1_000_000)
     pf = R.ParquetFile(buf)
     chunks, nc, pages, npg = pf.descriptors(0, 1)
     plan = R.decode_host(ctx, chunks, nc, pages, npg, pf.address, pf.size)
@@ -49,6 +49,14 @@ def test_optional_strings_1m_slot_pages(ctx):
 def test_person_friends_1m_row_pages(ctx):
     """Person{Being, Friends []Being}: friends.id (def/rep width 1/1) and friends.age (2/1), 2 pages of 1M rows."""
     _decode_and_verify(ctx, "nested", {"friends.age"})
+
+
+def test_document_and_deep_chain_1m_row_pages(ctx):
+    """The rest of the type list at full size: bools, float32, uint32 / uint64, and the level widths the Person columns
+    do not reach: the Dremel Document (doc.go:5-24: names.languages.country with definition levels up to 3 and
+    repetition levels up to 2, links.backward) and the five-deep chain a.b.c.d.e (definition levels up to 5: width 3),
+    one page of 1M rows each (2.9M and 2.2M levels), against the generator's inputs and the oracle."""
+    _decode_and_verify(ctx, "wide", {"names.languages.country", "a.b.c.d.e", "links.backward", "ob", "ou64"}, pages=1)
 
 
 def test_mixed_schema_row_group(ctx):

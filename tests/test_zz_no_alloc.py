@@ -6,6 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import oracle as O
 from parquet_amd import _native as N
 from parquet_amd import reader as R
 from parquet_amd.writer import encode_levels
@@ -60,6 +61,21 @@ def _compare(ctx, width, levels, max_values):
     assert np.array_equal(got[:n], want[:n])
     assert np.array_equal(want[:min(n, levels.size)], levels[:min(n, levels.size)])
     assert (got[n:] == 0xAB).all()  # nothing written past what the block holds
+    # and against the oracle's rle.Read (internal/rle/rle.go:159-195): the values the block holds (bit-packed tails
+    # count in full) and the first of them
+    ovals, oerr = _oracle_read(width, block)
+    assert oerr == 0 and n_got == ovals.size
+    assert np.array_equal(got[:n], ovals[:n])
+
+
+def _oracle_read(width, block):
+    """(values, error) of the oracle's rle.Read over a whole block (length prefix included)."""
+    try:
+        vals, consumed = O.rle_read(width, block)
+    except O.OracleError as e:
+        return np.zeros(0, np.uint8), e.code or 1
+    assert consumed == len(block)
+    return vals, 0
 
 
 def test_noalloc_matches_rle_decode_two_calls_second_smaller():
@@ -87,5 +103,16 @@ def test_noalloc_rejects_oversized_and_reports_corrupt():
         bad = np.array([4, 0, 0, 0, 0x03, 0xFF, 0x80, 0x80], np.uint8).tobytes()
         _, n, st = _noalloc(ctx, 1, bad, 100)
         assert st == N.E_CORRUPT and n == 0
+        assert _oracle_read(1, bad)[1] != 0  # io.EOF in the header for the reference too
+        # io.EOF on the value byte of an RLE run, and on the packed bytes of a bit-packed run
+        for blk in (np.array([1, 0, 0, 0, 0x10], np.uint8).tobytes(), np.array([1, 0, 0, 0, 0x03], np.uint8).tobytes()):
+            assert _oracle_read(1, blk)[1] != 0
+            _, n, st = _noalloc(ctx, 1, blk, 100)
+            assert st == N.E_CORRUPT and n == 0
+        # width 0: headers without payload bytes, values all zero (rle.go:198-201, 232-244)
+        blk = np.array([3, 0, 0, 0, 0x14, 0x05, 0x08], np.uint8).tobytes()  # RLE x10, bit-packed 2 groups, RLE x4
+        ovals, oerr = _oracle_read(0, blk)
+        got, n, st = _noalloc(ctx, 0, blk, 64)
+        assert oerr == 0 and st == 0 and n == ovals.size == 30 and not got[:n].any() and (got[n:] == 0xAB).all()
     finally:
         ctx.close()
