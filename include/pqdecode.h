@@ -202,9 +202,11 @@ int pqd_rle_decode(pqd_ctx* ctx, int width, const void* block, size_t block_len,
  *                  written), 0 or a negative pqd_status}
  * The tables of the decode live in a static device array of the library (about 50 KB per GPU, held until the
  * process ends), which limits a block to PQD_NOALLOC_MAX_BLOCK_BYTES of runs; larger blocks are refused with
- * PQD_E_ARG.  Every call on one GPU shares that array: calls that overlap on one GPU (two contexts, two
- * streams) race; calls on one context are ordered by its stream.  Read the results with pqd_copy_to_host,
- * which waits for the stream. */
+ * PQD_E_ARG.  Every call on one GPU shares that array.  Calls on one context are ordered by its stream; a call
+ * from another context of the same GPU is queued behind the call before it (an event the library keeps per GPU),
+ * so calls from several contexts or host threads do not overlap on the array, they take turns.  Code that
+ * launches the same work on streams of its own (a replayed graph) must keep that order itself: replays that
+ * overlap on one GPU race.  Read the results with pqd_copy_to_host, which waits for the stream. */
 #define PQD_NOALLOC_MAX_BLOCK_BYTES (16u << 20)
 int pqd_rle_decode_noalloc(pqd_ctx* ctx, int width, const void* runs_device, size_t runs_len,
                            void* out_device, size_t max_values, int64_t* result_device);

@@ -836,7 +836,11 @@ int pqd_plan_sync(pqd_plan* pl) {
     pl->last_status = map_status(pl->h_status[0]);
     if (pl->last_status) {
         char b[128];
-        snprintf(b, sizeof b, "decode failed: device status %d at item %d", pl->h_status[0], pl->h_status[1]);
+        if (pl->h_status[0] == ST_INTERNAL)
+            snprintf(b, sizeof b, "decode failed: a workgroup of block %d gave up waiting for tile %d (%s)", pl->h_status[1], pl->h_status[2],
+                     pl->h_status[3] == 0 ? "position" : pl->h_status[3] == 1 ? "value count" : "tile flag");
+        else
+            snprintf(b, sizeof b, "decode failed: device status %d at item %d", pl->h_status[0], pl->h_status[1]);
         ctx->err = b;
     }
     return pl->last_status;
@@ -1166,11 +1170,10 @@ int pqd_rle_decode_noalloc(pqd_ctx* ctx, int width, const void* runs_device, siz
     if (width < 0 || width > 8) return fail(ctx, PQD_E_ARG, "width must be 0..8 (one byte per value)");
     if (runs_len > PQD_NOALLOC_MAX_BLOCK) return fail(ctx, PQD_E_ARG, "level block larger than PQD_NOALLOC_MAX_BLOCK (16 MiB)");
     if (max_values > 0x7fffffffu) return fail(ctx, PQD_E_ARG, "max_values too large");
-    void* sc = lv_scratch_ptr(ctx->device);
-    if (!sc) return fail(ctx, PQD_E_HIP, "static scratch not initialised on this device");
+    if (!lv_scratch_ptr(ctx->device)) return fail(ctx, PQD_E_HIP, "static scratch not initialised on this device");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, launch_rle_decode_u8(ctx->stream, sc, width, (const u8*)runs_device, (u32)runs_len, (u8*)out_device, (u32)max_values,
-                                      (long long*)result_device));
+    HIP_TRY(ctx, launch_rle_decode_u8_static(ctx->device, ctx->stream, width, (const u8*)runs_device, (u32)runs_len, (u8*)out_device,
+                                             (u32)max_values, (long long*)result_device));
     return PQD_OK;
 }
 

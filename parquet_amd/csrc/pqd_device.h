@@ -50,7 +50,7 @@ constexpr u32 CH_SUPER = 16;      // groups per super-group (strings only)
 constexpr u32 chain_group_tiles(int kind) { return kind == KIND_LEVELS ? CH_G_LEVELS : kind == KIND_STRINGS ? CH_G_STRINGS : CH_G_SNAPPY; }
 
 constexpr u32 OT = 4096;          // level values per expand tile
-constexpr u32 SN_SPIN_MAX = 1u << 22;  // snappy: polls of an earlier tile's flag before a workgroup gives up (safety net, never reached)
+constexpr unsigned long long SN_WAIT_TICKS = 200000000ull;  // snappy: a workgroup waits this long (100 MHz wall clock: 2 s) for an earlier tile's flag, then gives up
 constexpr u32 SN_T = 32768;       // snappy: output bytes per decode tile (half the block size of the usual encoders: 15-bit tile positions)
 constexpr u32 EX_CAP = 1024;      // runs staged in LDS per expand batch
 constexpr u32 BT = 4096;          // bools per tile
@@ -183,7 +183,7 @@ constexpr u32 LV_THREADS = LV_T / 16;     // one 16-byte sub-tile per thread
 constexpr u32 LV_T_SMALL_BATCH = 8192, LV_T_LARGE_BATCH = 4096;
 constexpr u32 LV_LARGE_BATCH_TILES = 1000;  // a batch of more 8 KiB super-tiles than this takes the 4 KiB build (optional int32, 10 % nulls: 608 super-tiles 71 vs 73 us, 1216: 104 vs 98 us, 2432: 177 vs 146 us)
 constexpr u32 LV_SUB = LV_T / LV_THREADS;
-constexpr u32 LV_SPIN_MAX = 1u << 22;  // polls of a granule before a workgroup gives up (safety net, never reached)
+constexpr unsigned long long LV_WAIT_TICKS = 200000000ull;  // a workgroup waits this long (100 MHz wall clock: 2 s) for a granule, then gives up
 struct LvTile { u32 region, index; };  // launch order: super-tile `index` of `region`; predecessors come first
 struct LvArgs {
     const Region* regions;
@@ -209,6 +209,9 @@ void* lv_scratch_ptr(int device);
 size_t lv_scratch_bytes(size_t runs_len);
 hipError_t launch_rle_decode_u8(hipStream_t st, void* scratch, int width, const u8* runs, u32 len, u8* out, u32 max_values,
                                 long long* result_device);
+// the same over the device's static scratch; calls from different streams are queued behind each other
+hipError_t launch_rle_decode_u8_static(int device, hipStream_t st, int width, const u8* runs, u32 len, u8* out, u32 max_values,
+                                       long long* result_device);
 
 hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks, const PageRec* pages, u32 n_pages,
                             PageDyn* page_dyn, ChunkDyn* chunk_dyn, int* status);

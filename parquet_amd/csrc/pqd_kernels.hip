@@ -2356,7 +2356,10 @@ __global__ __launch_bounds__(SP_THREADS) void k_snappy_ptr(const u8* __restrict_
                                                            const u32* __restrict__ otile_region, const RunRec* __restrict__ run_tbl,
                                                            const u32* __restrict__ otile_first_run,
                                                            const RegionTotal* __restrict__ totals, int* __restrict__ status,
-                                                           u32* __restrict__ tile_done, u32* __restrict__ ticket, u32 n_otiles) {
+                                                           u32* __restrict__ tile_done, u32* __restrict__ ticket, u32 n_otiles, u32 strict) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_snappy_ptr hands a tile's bytes to later tiles with device-scope stores, a wait for them (vmcnt) and a relaxed flag: that is ordered on gfx950; check it (or build with strict = 1 semantics) before compiling for another target"
+#endif
     __shared__ __attribute__((aligned(16))) unsigned short s_x[SN_T];
     __shared__ u32 s_long[3 * SP_LONG_MAX];
     __shared__ u32 s_ticket, s_nlong, s_far_lo;
@@ -2495,13 +2498,15 @@ __global__ __launch_bounds__(SP_THREADS) void k_snappy_ptr(const u8* __restrict_
         const u32 q0 = far_lo / SN_T, q1 = B / SN_T;  // tiles q0 .. q1 - 1 of the block hold them
         bool ok = true;
         for (u32 q = q0 + tid; q < q1 && ok; q += SP_THREADS) {
-            u32 spins = 0;
-            while (!__hip_atomic_load(tile_done + R.otile_base + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                if (++spins > SN_SPIN_MAX) { ok = false; break; }
+            // a wait is bounded by time, not by polls: SN_WAIT_TICKS of the 100 MHz wall clock
+            const u64 t_wait = wall_clock64();
+            while (!(strict ? __hip_atomic_load(tile_done + R.otile_base + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+                            : __hip_atomic_load(tile_done + R.otile_base + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (wall_clock64() - t_wait > SN_WAIT_TICKS) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(4);
             }
+            if (!ok && atomicCAS(status, 0, ST_INTERNAL) == 0) { status[1] = (int)ri; status[2] = (int)(R.otile_base + q); status[3] = (int)ot; }  // who waited for whom
         }
-        if (!ok) set_status(status, ST_INTERNAL, ri);
         __syncthreads();
         // The other tiles' bytes were stored with device-scope stores before their flags went up (below); device-scope
         // loads read them without a cache invalidate.
@@ -2561,7 +2566,12 @@ __global__ __launch_bounds__(SP_THREADS) void k_snappy_ptr(const u8* __restrict_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the stores above have been performed at device scope
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(tile_done + ot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // strict: a release store at device scope (writes the L2 back, slow) paired with acquire loads of the flag: the
+    // textbook ordering, to compare with when a result is ever in doubt
+    if (tid == 0) {
+        if (strict) __hip_atomic_store(tile_done + ot, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(tile_done + ot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Level block sizes of pages whose payload only exists on the device (decompressed pages): the int32
@@ -2921,9 +2931,10 @@ hipError_t launch_snappy_tiles(hipStream_t st, const u8* src, const Region* regi
                                const RunRec* run_tbl, const u32* otile_first_run, const RegionTotal* totals, int* status,
                                u32* tile_done) {
     if (n_otiles == 0) return hipSuccess;
+    static const u32 strict = getenv("PQD_SNAPPY_STRICT") && atoi(getenv("PQD_SNAPPY_STRICT")) ? 1u : 0u;  // diagnostics, see the kernel
     // tile_done: n_otiles flags and the ticket counter behind them, all zero
     hipLaunchKernelGGL(k_snappy_ptr, dim3(n_otiles), dim3(SP_THREADS), 0, st, src, regions, otile_region, run_tbl, otile_first_run,
-                       totals, status, tile_done, tile_done + n_otiles, n_otiles);
+                       totals, status, tile_done, tile_done + n_otiles, n_otiles, strict);
     LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "pqd_device.h"
@@ -200,13 +201,19 @@ static __device__ __forceinline__ u64 lv_zero_bytes(u64 x) {
     return ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) & 0x8080808080808080ull;
 }
 
+// waits for a granule; bounded by time (profilers and other tenants stretch a wait, not its polls): 0 = gave up
 static __device__ __forceinline__ u64 lv_poll(const u64* g) {
-    for (u32 spins = 0; spins < LV_SPIN_MAX; spins++) {
+    const u64 t0 = wall_clock64();
+    for (;;) {
         const u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (x >> 32) return x;
+        if (wall_clock64() - t0 > LV_WAIT_TICKS) return 0;
         __builtin_amdgcn_s_sleep(2);
     }
-    return 0;
+}
+// a wait that ran out: status = {ST_INTERNAL, region, super-tile waited for, 0 position granule / 1 value granule}
+static __device__ __forceinline__ void lv_timeout(int* status, u32 region, u32 tile, int which) {
+    if (atomicCAS(status, 0, ST_INTERNAL) == 0) { status[1] = (int)region; status[2] = (int)tile; status[3] = which; }
 }
 static __device__ __forceinline__ void lv_publish(u64* g, u32 v) {
     __hip_atomic_store(g, (1ull << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
         LV_STAMP(5);
         lv_publish(a.pos_g + R.lv_base + j, ex);
         LV_STAMP(6);
-        if (timeout) set_status(a.status, ST_INTERNAL, ot.region);
+        if (timeout) lv_timeout(a.status, ot.region, j - 1, 0);
         else if (ex == ERR_POS && e != ERR_POS) set_status(a.status, ST_CORRUPT, ot.region);
         s_e = e;
         s_ex = ex;
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
         LV_STAMP(10);
         const u64 incl = (u64)prefix + tot_v;
         lv_publish(a.val_g + R.lv_base + j, incl < 0xFFFFFFFFull ? (u32)incl : 0xFFFFFFFFu);
-        if (timeout) set_status(a.status, ST_INTERNAL, ot.region);
+        if (timeout) lv_timeout(a.status, ot.region, j - 1, 1);
         else if (last && incl < n_out && !(R.otile_base & LV_ALLOW_SHORT)) set_status(a.status, ST_CORRUPT, ot.region);  // defs[:NumValues] out of range
         s_prefix = prefix;
         s_bad = 0;
@@ -848,18 +855,53 @@ constexpr size_t LVS_STATIC_BYTES = sizeof(LvsHead) + (size_t)LVS_MAX_TILES * (s
 // hipGetSymbolAddress: the device address is looked up once per device (lv_scratch_init) and used from then on.
 static __device__ __align__(256) unsigned char scratch[LVS_STATIC_BYTES];
 constexpr int LVS_MAX_DEVICES = 64;
-static void* g_scratch_ptr[LVS_MAX_DEVICES];
+// Per device: the array's address, and who used it last.  Contexts are created from any host thread (one per reader), and
+// every context of a device shares the array: the slot is filled under its mutex, and a call that comes on another stream
+// than the call before it is queued behind that call's event, so overlapping calls are serialised on the device
+// instead of racing on the tables.
+hipError_t launch_rle_decode_u8(hipStream_t st, void* sc_, int width, const u8* runs, u32 len, u8* out, u32 max_values,
+                                long long* result_device);
+struct LvScratchSlot {
+    std::mutex mu;
+    void* ptr = nullptr;
+    hipEvent_t done = nullptr;     // recorded behind the last call's kernels
+    hipStream_t last = nullptr;    // the stream of that call
+    bool used = false;
+};
+static LvScratchSlot g_scratch[LVS_MAX_DEVICES];
 
 hipError_t lv_scratch_init(int device) {  // the device is current
     if (device < 0 || device >= LVS_MAX_DEVICES) return hipErrorInvalidDevice;
-    if (g_scratch_ptr[device]) return hipSuccess;
+    LvScratchSlot& S = g_scratch[device];
+    std::lock_guard<std::mutex> lock(S.mu);
+    if (S.ptr) return hipSuccess;
     void* ptr = nullptr;
-    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess) return e;
-    g_scratch_ptr[device] = ptr;
+    e = hipEventCreateWithFlags(&S.done, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+    S.ptr = ptr;
     return hipSuccess;
 }
-void* lv_scratch_ptr(int device) { return device >= 0 && device < LVS_MAX_DEVICES ? g_scratch_ptr[device] : nullptr; }
+void* lv_scratch_ptr(int device) {
+    if (device < 0 || device >= LVS_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch[device].mu);
+    return g_scratch[device].ptr;
+}
+// One decode over the device's static scratch, queued on `st` (no allocation: the event exists since lv_scratch_init).
+hipError_t launch_rle_decode_u8_static(int device, hipStream_t st, int width, const u8* runs, u32 len, u8* out, u32 max_values,
+                                       long long* result_device) {
+    if (device < 0 || device >= LVS_MAX_DEVICES) return hipErrorInvalidDevice;
+    LvScratchSlot& S = g_scratch[device];
+    std::lock_guard<std::mutex> lock(S.mu);
+    if (!S.ptr) return hipErrorNotInitialized;
+    hipError_t e = hipSuccess;
+    if (S.used && S.last != st) e = hipStreamWaitEvent(st, S.done, 0);  // behind the call before, whoever made it
+    if (e == hipSuccess) e = launch_rle_decode_u8(st, S.ptr, width, runs, len, out, max_values, result_device);
+    if (e == hipSuccess) e = hipEventRecord(S.done, st);
+    if (e == hipSuccess) { S.last = st; S.used = true; }
+    return e;
+}
 size_t lv_scratch_bytes(size_t runs_len) { return lvs_bytes(lvs_tiles(runs_len)); }
 
 __global__ void k_lv_setup(unsigned char* sc, u32 n_tiles, u32 width, u32 len, u8* out, u32 max_values) {

@@ -235,3 +235,32 @@ def test_random_element_streams_with_a_wide_window(ctx, seed):
     got = R.snappy_decode_blocks(ctx, blocks)
     for i, (g, w) in enumerate(zip(got, wants)):
         assert g == w, (seed, i)
+
+
+def test_fuzz_blocks_of_every_kind():
+    """A short run of tools/fuzz_snappy.py in the suite (the long runs stay under tools/): payloads of several kinds from
+    two encoders and hand-built element streams with copies across tiles, against the oracle."""
+    import importlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    fuzz = importlib.import_module("fuzz_snappy")
+    ctx = R.Context(0)
+    try:
+        for seed in range(12):
+            fuzz.one(ctx, seed)
+    finally:
+        ctx.close()
+
+
+def test_fuzz_blocks_with_release_acquire_flags():
+    """The same with PQD_SNAPPY_STRICT=1: tiles hand their bytes over with a release store and acquire loads of the flag
+    instead of device-scope stores and a wait for them.  Both orderings must decode the same bytes (the switch is read once
+    per process, hence the child process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_snappy.py"), "100", "6"], env=dict(os.environ, PQD_SNAPPY_STRICT="1"),
+                         capture_output=True, text=True, timeout=250)
+    assert out.returncode == 0 and "seeds 100..105 ok" in out.stdout, out.stderr[-1500:]

@@ -116,3 +116,36 @@ def test_noalloc_rejects_oversized_and_reports_corrupt():
         assert oerr == 0 and st == 0 and n == ovals.size == 30 and not got[:n].any() and (got[n:] == 0xAB).all()
     finally:
         ctx.close()
+
+
+def test_noalloc_calls_from_two_contexts_take_turns():
+    """Two contexts of one GPU share the static scratch: calls queued on both without waiting in between are serialised
+    by the library (each is queued behind the one before it), so both decode their own block."""
+    rng = np.random.default_rng(79)
+    ca, cb = R.Context(0), R.Context(0)
+    try:
+        jobs = []
+        for ctx, n, width in ((ca, 900_000, 1), (cb, 700_000, 2), (ca, 5_000, 3), (cb, 1_200_000, 1)):
+            levels = _levels(rng, n, width, 0.4)
+            block = encode_levels(width, levels)
+            runs = np.frombuffer(block, np.uint8)[4:].copy()
+            d_runs = N.decode.pqd_device_alloc(ctx.handle, runs.size)
+            d_out = N.decode.pqd_device_alloc(ctx.handle, n)
+            d_res = N.decode.pqd_device_alloc(ctx.handle, 16)
+            assert N.decode.pqd_copy_to_device(ctx.handle, d_runs, runs.ctypes.data, runs.size) == 0
+            jobs.append((ctx, levels, block, width, d_runs, runs.size, d_out, d_res))
+        for ctx, levels, block, width, d_runs, nr, d_out, d_res in jobs:  # all queued before any result is read
+            assert N.decode.pqd_rle_decode_noalloc(ctx.handle, width, d_runs, nr, d_out, levels.size, d_res) == 0
+        for ctx, levels, block, width, d_runs, nr, d_out, d_res in jobs:
+            res = np.zeros(2, np.int64)
+            out = np.zeros(levels.size, np.uint8)
+            assert N.decode.pqd_copy_to_host(ctx.handle, res.ctypes.data, d_res, 16) == 0
+            assert N.decode.pqd_copy_to_host(ctx.handle, out.ctypes.data, d_out, out.size) == 0
+            ovals, oerr = _oracle_read(width, block)
+            assert oerr == 0 and res[1] == 0 and res[0] == ovals.size
+            assert np.array_equal(out, ovals[:levels.size]) and np.array_equal(out, levels)
+            for p in (d_runs, d_out, d_res):
+                N.decode.pqd_device_free(ctx.handle, p)
+    finally:
+        ca.close()
+        cb.close()
