@@ -135,8 +135,10 @@ def gen_nested_levels(types, n_rows, rng, p_null=0.25, max_count=3):
     return defs.astype(np.uint8), reps
 
 
-def _gen_page(N, name, rng, n):
-    """One page of `n` rows of the named column: (values, defs, reps, offsets)."""
+def _gen_page(N, name, rng, n, srng=None):
+    """One page of `n` rows of the named column: (values, defs, reps, offsets).  srng: the generator that draws how many
+    friends a row has; friends.id and friends.age of one page get the same one (they are fields of the same friends, so
+    their repetition levels are the same, as in any file of that schema)."""
     if name in ("f32", "of32", "u32", "ou64"):
         mask = rng.random(n) >= 0.1 if name[0] == "o" else None
         nv = int(mask.sum()) if mask is not None else n
@@ -186,7 +188,7 @@ def _gen_page(N, name, rng, n):
         mask = rng.random(n) >= 0.5
         return rng.integers(0, 100, int(mask.sum()), dtype=np.int64).astype(np.int32), mask.astype(np.uint8), None, None
     # friends.id / friends.age: 0-3 friends per row (as _examples/people/people.go:72), age null 50 %
-    k = rng.integers(0, 4, n)
+    k = (srng if srng is not None else rng).integers(0, 4, n)
     nl = np.maximum(k, 1)
     starts = np.zeros(n + 1, np.int64)
     np.cumsum(nl, out=starts[1:])
@@ -221,8 +223,8 @@ def build_file(workload, rg_ids, pages, rows_per_page):
         keep = gi == 0 or gi == len(rg_ids) - 1
         w.begin_row_group()
         for ci, c in enumerate(cols):
-            for _ in range(pages):
-                v, d, r, o = _gen_page(N, c.path, rng, rows_per_page)
+            for pi in range(pages):
+                v, d, r, o = _gen_page(N, c.path, rng, rows_per_page, np.random.default_rng([seed0 + g, pi, 99]))
                 w.write_page(ci, v, defs=d, reps=r, offsets=o)
                 ex.page(gi, ci, keep, v, d, r, o)
         w.end_row_group(pages * rows_per_page)
@@ -476,12 +478,15 @@ def main():
     # never part of `value`: validity bitmap (N / 8) and value index (4 bytes per 64 levels) of the optional chunks,
     # the two int32 row-offset arrays of the repeated chunks
     extra = 0
+    seen_rl = set()
     for k in range(ld.nc):
         cd, ci = ld.chunks[k], ld.plan.info(k)
         if cd.max_def > 0:
             extra += (ci.n_levels + 7) // 8 + 4 * ((ci.n_levels + 63) // 64 + 1)
-        if cd.max_rep > 0:
-            extra += 2 * 4 * (ci.n_rows + 1)
+        if cd.max_rep > 0:  # a chunk that shares another chunk's repetition levels shares its row_level_off: written once
+            rl = ld.plan.device_ptr(k, ld.N.OUT_ROW_LEVEL_OFF)
+            extra += (4 if rl in seen_rl else 8) * (ci.n_rows + 1)
+            seen_rl.add(rl)
     alg_t = torch.tensor([alg], dtype=torch.int64, device=coll_dev)
     if use_dist:
         dist.all_reduce(alg_t)
@@ -536,6 +541,7 @@ def main():
             },
             "device_ms_per_step_events": round(step_ms, 4),
             "string_chunks_through_two_passes": ld.plan.string_fallbacks(),
+            "chunks_sharing_repetition_levels": int(ld.N.decode.pqd_plan_shared_reps(ld.plan._h)),
             "setup_seconds": round(t_build, 1),
         }
         if world == 1 and not args.no_cpu_baseline:  # the CPU legs are timed on a single-GPU run only

@@ -182,6 +182,11 @@ int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                const void* src_host, size_t src_len, pqd_plan** out);
 /* Bytes pqd_decode copied from host to device for this plan (0 for a plan made by pqd_plan_create). */
 int64_t pqd_plan_h2d_bytes(pqd_plan* plan);
+/* Column chunks of the plan whose repetition level blocks are byte for byte those of an earlier chunk of the batch
+ * (leaves under the same repeated groups, e.g. Friends.ID and Friends.Age of README.md:146-159): their PQD_OUT_REPS and
+ * PQD_OUT_ROW_LEVEL_OFF are that chunk's arrays (the same device pointers), decoded and written once.  Found only for
+ * blocks the planner located through `src_host` itself; PQD_SHARE_REPS=0 in the environment turns it off. */
+int64_t pqd_plan_shared_reps(pqd_plan* plan);
 
 /* ---- standalone level decode: rle.Read (internal/rle/rle.go:159-195) for one block ----------
  * `block` = int32 LE length + runs, in host memory.  width 0..32; out_elem_size 1 (width <= 8),

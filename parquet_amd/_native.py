@@ -86,6 +86,7 @@ DECODE_SYMBOLS = {
     "pqd_plan_scatter": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t]),
     "pqd_plan_string_fallbacks": (C.c_int64, [_P]),
     "pqd_plan_h2d_bytes": (C.c_int64, [_P]),
+    "pqd_plan_shared_reps": (C.c_int64, [_P]),
     "pqd_plan_debug_stamps": (C.c_int64, [_P, _P, C.c_size_t]),
     "pqd_decode": (C.c_int, [_P, C.POINTER(ChunkDesc), C.c_size_t, C.POINTER(PageDesc), C.c_size_t,
                              _P, C.c_size_t, C.POINTER(_P)]),

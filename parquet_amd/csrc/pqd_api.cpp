@@ -54,6 +54,7 @@ struct pqd_plan {
     size_t src_len = 0;
     u8* owned_src = nullptr;       // device copy made by pqd_decode
     int64_t h2d_bytes = 0;         // bytes pqd_decode copied to the device for this plan
+    int n_shared_rep = 0;          // chunks whose repetition levels are another chunk's (byte-identical blocks)
     const u8* last_src = nullptr;
 
     // host copies of the tables
@@ -266,6 +267,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     std::vector<u32> rep_bytes(n_pages, 0), def_bytes(n_pages, 0);
     std::vector<u64> lvl_off(n_pages, 0), val_stream_off(n_pages, 0), payload_off(n_pages, 0);
     std::vector<char> page_seen(n_pages, 0);
+    std::vector<char> rep_on_host(n_pages, 0);  // the page's repetition level block was located through src_host: its bytes lie there
 
     // ---- validate descriptors; locate the level blocks and the values region of every page
     for (size_t c = 0; c < n_chunks; c++) {
@@ -311,6 +313,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                     memcpy(&len, src_host + pd.src_off + l, 4);
                     if (len < 0) return fail(ctx, PQD_E_CORRUPT, "negative level block length");
                     given = (int32_t)((int64_t)len + 4 > 0x7fffffff ? 0x7fffffff : len + 4);
+                    if (lv == 0) rep_on_host[pi] = 1;
                 }
                 if (given < 4 || l + (u64)given > (u64)pd.payload_len)
                     return fail(ctx, PQD_E_CORRUPT, "level block runs past the page payload");
@@ -346,6 +349,48 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     for (size_t p = 0; p < n_pages; p++)
         if (!page_seen[p]) return fail(ctx, PQD_E_ARG, "page not owned by any chunk");
 
+    // Leaves under the same repeated groups carry the same repetition levels (Person.Friends.ID and .Age: one level
+    // per friend in both), and a deterministic writer encodes them to the same bytes.  A chunk whose repetition level
+    // blocks are byte for byte those of an earlier chunk of the batch (same pages, same value counts) shares that
+    // chunk's decoded REPS, its row starts and its ROW_LEVEL_OFF instead of having them decoded and written again.
+    // Only where the planner has the bytes at hand (blocks it located through src_host itself).
+    std::vector<int> twin_of(n_chunks, -1);
+    {
+        const char* sh = getenv("PQD_SHARE_REPS");
+        const bool share = !sh || atoi(sh) != 0;
+        std::vector<std::pair<u64, size_t>> sigs;  // (signature, chunk) of the chunks that can be shared with
+        for (size_t c = 0; c < n_chunks && share && src_host; c++) {
+            const ChunkRec& C = pl->chunks[c];
+            if (C.max_rep <= 0 || C.n_pages == 0) continue;
+            bool ok = true;
+            u64 sig = 0xcbf29ce484222325ull ^ ((u64)C.max_rep << 32) ^ C.n_pages;
+            for (u32 k = 0; k < C.n_pages && ok; k++) {
+                const size_t pi = C.first_page + k;
+                ok = rep_on_host[pi] != 0;
+                if (!ok) break;
+                const u8* b = src_host + payload_off[pi];
+                const u32 nb = rep_bytes[pi];
+                sig = (sig ^ nb ^ ((u64)pl->pages[pi].num_values << 32)) * 0x100000001b3ull;
+                u32 i = 0;
+                for (; i + 8 <= nb; i += 8) { u64 x; memcpy(&x, b + i, 8); sig = (sig ^ x) * 0x9E3779B97F4A7C15ull; sig ^= sig >> 29; }
+                for (; i < nb; i++) sig = (sig ^ b[i]) * 0x100000001b3ull;
+            }
+            if (!ok) continue;
+            for (const auto& e : sigs) {
+                if (e.first != sig) continue;
+                const ChunkRec& D = pl->chunks[e.second];
+                bool same = D.max_rep == C.max_rep && D.n_pages == C.n_pages && D.n_levels == C.n_levels;
+                for (u32 k = 0; k < C.n_pages && same; k++) {
+                    const size_t pa = C.first_page + k, pb = D.first_page + k;
+                    same = rep_bytes[pa] == rep_bytes[pb] && pl->pages[pa].num_values == pl->pages[pb].num_values &&
+                           memcmp(src_host + payload_off[pa], src_host + payload_off[pb], rep_bytes[pa]) == 0;
+                }
+                if (same) { twin_of[c] = (int)e.second; break; }
+            }
+            if (twin_of[c] < 0) sigs.emplace_back(sig, c);
+        }
+    }
+
     // ---- size the outputs and the scratch tables
     ArenaPlan ap;
     std::vector<size_t> off_out(n_chunks * N_OUT, (size_t)-1);
@@ -362,8 +407,13 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
             want(PQD_OUT_VALUE_INDEX, ((C.n_levels + 63) / 64 + 1) * 4);
         }
         if (C.max_rep > 0) {
-            want(PQD_OUT_REPS, C.n_levels);
-            want(PQD_OUT_ROW_LEVEL_OFF, (C.n_levels + 1) * 4);
+            if (twin_of[c] < 0) {
+                want(PQD_OUT_REPS, C.n_levels);
+                want(PQD_OUT_ROW_LEVEL_OFF, (C.n_levels + 1) * 4);
+            } else {  // shared with the twin (patched below)
+                cap[PQD_OUT_REPS] = C.n_levels;
+                cap[PQD_OUT_ROW_LEVEL_OFF] = (C.n_levels + 1) * 4;
+            }
             want(PQD_OUT_ROW_VALUE_OFF, (C.n_levels + 1) * 4);
         }
         if (C.width_bytes) want(PQD_OUT_VALUES, C.stream_len);
@@ -415,6 +465,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
             for (int lv = 0; lv < 2; lv++) {
                 const u32 nb = lv == 0 ? rep_bytes[pi] : def_bytes[pi];
                 if (!nb) continue;
+                if (lv == 0 && twin_of[c] >= 0) { l += nb; continue; }  // decoded with the twin's
                 Region R;
                 memset(&R, 0, sizeof R);
                 R.src_off = payload_off[pi] + l + 4;
@@ -548,7 +599,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         if (pl->chunks[c].max_def > 0) off_out[c * N_OUT + PQD_OUT_VALIDITY] = ap.take(pl->outs[c].cap[PQD_OUT_VALIDITY] + 64);
     std::vector<size_t> off_rstarts(n_chunks, (size_t)-1);  // row-start bitmaps of the repeated chunks, same treatment
     for (size_t c = 0; c < n_chunks; c++)
-        if (pl->chunks[c].max_rep > 0) off_rstarts[c] = ap.take((pl->chunks[c].n_levels + 7) / 8 + 64);
+        if (pl->chunks[c].max_rep > 0 && twin_of[c] < 0) off_rstarts[c] = ap.take((pl->chunks[c].n_levels + 7) / 8 + 64);
     const size_t o_status = ap.take(16);
     const size_t o_lvticket = ap.take(16);
     const size_t o_lvpos = ap.take((size_t)pl->n_lvtiles * 8), o_lvval = ap.take((size_t)pl->n_lvtiles * 8);  // hand-off granules
@@ -586,6 +637,16 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
             pl->outs[c].p[w] = *ptrs[w];
         }
         C.row_starts = off_rstarts[c] == (size_t)-1 ? nullptr : A + off_rstarts[c];
+    }
+    for (size_t c = 0; c < n_chunks; c++) {
+        if (twin_of[c] < 0) continue;
+        ChunkRec& C = pl->chunks[c];
+        const ChunkRec& T = pl->chunks[(size_t)twin_of[c]];  // an earlier chunk, never a twin itself
+        C.reps = T.reps; C.row_starts = T.row_starts; C.row_level_off = T.row_level_off;
+        C.shares_rep = 1;
+        pl->outs[c].p[PQD_OUT_REPS] = T.reps;
+        pl->outs[c].p[PQD_OUT_ROW_LEVEL_OFF] = T.row_level_off;
+        pl->n_shared_rep++;
     }
     for (Region& R : pl->lregions) {
         const ChunkRec& C = pl->chunks[pl->pages[R.page].chunk];
@@ -946,6 +1007,7 @@ int pqd_plan_scatter(pqd_plan* pl, size_t c, void* dst_device, size_t dst_bytes)
 }
 
 int64_t pqd_plan_h2d_bytes(pqd_plan* pl) { return pl ? pl->h2d_bytes : PQD_E_ARG; }
+int64_t pqd_plan_shared_reps(pqd_plan* pl) { return pl ? pl->n_shared_rep : PQD_E_ARG; }
 
 int64_t pqd_plan_string_fallbacks(pqd_plan* pl) {
     if (!pl || !pl->synced) return PQD_E_ARG;

@@ -101,6 +101,8 @@ struct ChunkRec {
     u64 req_values;   // required chunk: parquet.Page.N, the number of values the typed Read takes
     u8 *defs, *reps, *values, *offsets, *chars, *validity, *page_nonnull, *row_level_off, *row_value_off, *value_index;
     u8* row_starts;   // repeated chunks: bit i = level i has repetition level 0 (written by the level decode, read by k_rows)
+    u32 shares_rep;   // reps, row_starts and row_level_off are those of another chunk with byte-identical repetition level blocks: not written for this one
+    u32 pad2;
 };
 struct ChunkDyn {
     u64 n_values, chars, n_rows;

@@ -2691,9 +2691,13 @@ __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunk
     // int32: a chunk holds fewer than 2^31 levels (checked when the plan is made)
     int32_t* rl = (int32_t*)C.row_level_off + T.row_base;
     int32_t* rv = (int32_t*)C.row_value_off + T.row_base;
-    for (u32 j = threadIdx.x; j < tot_r; j += 256) {
-        rl[j] = (int32_t)(lvl0 + s_rl[j]);
-        rv[j] = (int32_t)(T.val_base + s_rv[j]);
+    if (C.shares_rep) {  // the level offsets are the twin chunk's
+        for (u32 j = threadIdx.x; j < tot_r; j += 256) rv[j] = (int32_t)(T.val_base + s_rv[j]);
+    } else {
+        for (u32 j = threadIdx.x; j < tot_r; j += 256) {
+            rl[j] = (int32_t)(lvl0 + s_rl[j]);
+            rv[j] = (int32_t)(T.val_base + s_rv[j]);
+        }
     }
 }
 
@@ -2734,7 +2738,7 @@ __global__ __launch_bounds__(1024) void k_rows_scan(const ChunkRec* __restrict__
     }
     if (tid == 0) {
         chunk_dyn[c].n_rows = tot_r;
-        ((int32_t*)C.row_level_off)[tot_r] = (int32_t)C.n_levels;
+        if (!C.shares_rep) ((int32_t*)C.row_level_off)[tot_r] = (int32_t)C.n_levels;
         ((int32_t*)C.row_value_off)[tot_r] = (int32_t)tot_v;
     }
 }

@@ -858,3 +858,69 @@ def test_stream_schedules_give_the_same_results(monkeypatch, env, with_strings):
             plan.close()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("share", ["1", "0"])
+def test_sibling_leaves_share_their_repetition_levels(monkeypatch, share):
+    """Friends.ID and Friends.Age (README.md:146-159) have one level per friend each: byte-identical repetition level
+    blocks.  The decoder decodes them once and both chunks hand out the same REPS and ROW_LEVEL_OFF; with PQD_SHARE_REPS=0
+    each chunk gets its own.  Either way every array equals the oracle's.  A third repeated column with other levels, and a
+    sibling whose pages are cut differently, share nothing."""
+    monkeypatch.setenv("PQD_SHARE_REPS", share)
+    rng = np.random.default_rng(91)
+    cols = [Column("friends.id", N.INT32, [2, 0]), Column("friends.age", N.INT32, [2, 1]), Column("friends.nick", N.BYTE_ARRAY, [2, 1]),
+            Column("tags", N.BYTE_ARRAY, [2])]
+    w = ParquetWriter(cols, stats=False)
+    n_rows = 30000
+    for g in range(2):
+        w.begin_row_group()
+        k = rng.integers(0, 4, n_rows)
+        nl = np.maximum(k, 1)
+        starts = np.zeros(n_rows + 1, np.int64)
+        np.cumsum(nl, out=starts[1:])
+        reps = np.ones(int(starts[-1]), np.uint8)
+        reps[starts[:-1]] = 0
+        present = np.repeat(k > 0, nl)
+        cut = int(starts[n_rows // 2])  # a page boundary on a row boundary
+        for ci in range(4):
+            if ci == 3:  # other levels altogether
+                d2, r2, nv = H.gen_levels([2], 3000, rng)
+                lens = rng.integers(0, 9, nv)
+                offs = np.zeros(nv + 1, np.int32)
+                np.cumsum(lens, out=offs[1:])
+                w.write_page(ci, rng.integers(97, 123, int(offs[-1]), dtype=np.uint8), defs=d2, reps=r2, offsets=offs)
+                continue
+            if ci == 0:
+                defs = present.astype(np.uint8)
+            else:
+                defs = present.astype(np.uint8) + (present & (rng.random(reps.size) >= 0.4)).astype(np.uint8)
+            md = cols[ci].max_def
+            bounds = [0, cut, reps.size] if ci != 2 else [0, int(starts[n_rows // 3]), reps.size]  # friends.nick: other pages
+            for a, b in zip(bounds[:-1], bounds[1:]):
+                nv = int((defs[a:b] == md).sum())
+                if ci == 2:
+                    lens = rng.integers(1, 12, nv)
+                    offs = np.zeros(nv + 1, np.int32)
+                    np.cumsum(lens, out=offs[1:])
+                    w.write_page(ci, rng.integers(97, 123, int(offs[-1]), dtype=np.uint8), defs=defs[a:b], reps=reps[a:b], offsets=offs)
+                else:
+                    w.write_page(ci, rng.integers(0, 100, nv, dtype=np.int64).astype(np.int32), defs=defs[a:b], reps=reps[a:b])
+        w.end_row_group(n_rows)
+    buf = w.finish()
+    w.close()
+    c = R.Context(0)
+    try:
+        H.check_file(buf, c)
+        pf = R.ParquetFile(buf)
+        chunks, nc, pages, npg = pf.descriptors(0, pf.num_row_groups)
+        plan = R.decode_host(c, chunks, nc, pages, npg, pf.address, pf.size)
+        try:
+            assert N.decode.pqd_plan_shared_reps(plan._h) == (2 if share == "1" else 0)  # friends.age of both row groups
+            same = plan.device_ptr(0, N.OUT_REPS) == plan.device_ptr(1, N.OUT_REPS)
+            assert same == (share == "1")
+            assert plan.device_ptr(0, N.OUT_REPS) != plan.device_ptr(3, N.OUT_REPS)
+            assert plan.device_ptr(0, N.OUT_ROW_VALUE_OFF) != plan.device_ptr(1, N.OUT_ROW_VALUE_OFF)
+        finally:
+            plan.close()
+    finally:
+        c.close()

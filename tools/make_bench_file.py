@@ -30,8 +30,7 @@ def main():
             for p0 in range(g0, g1, per_page):
                 n = min(g1, p0 + per_page) - p0
                 # friends.id and friends.age of a row hold the same friends: the same draw of their number for both
-                rng = np.random.default_rng([7, p0, 3 if c.path.startswith("friends") else ci])
-                v, d, r, o = bench._gen_page(N, c.path, rng, n)
+                v, d, r, o = bench._gen_page(N, c.path, np.random.default_rng([7, p0, ci]), n, np.random.default_rng([7, p0, 99]))
                 w.write_page(ci, v, defs=d, reps=r, offsets=o)
         w.end_row_group(g1 - g0)
     buf = w.finish()
