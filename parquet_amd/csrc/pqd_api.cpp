@@ -774,7 +774,7 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     hipStream_t st = ctx->stream;
     const u32 n_chunks = (u32)pl->chunks.size(), n_pages = (u32)pl->pages.size();
     const u32 n_lreg = (u32)pl->lregions.size(), n_sreg = (u32)pl->sregions.size();
-    if (pl->n_stiles_chain)
+    if (pl->n_stiles_chain && !pl->schain.str_stat)  // behind the single pass the tables are reset on the device, and only when needed
         HIP_TRY(ctx, hipMemsetAsync(pl->ff_begin, 0xFF, pl->ff_bytes, st));
     HIP_TRY(ctx, hipMemsetAsync(pl->zero_begin, 0, pl->zero_bytes, st));
     if (ctx->str_giveup && pl->schain.str_failed) {
@@ -801,7 +801,7 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     if (n_sreg) {
         if (str_early) HIP_TRY(ctx, hipStreamWaitEvent(sst, pl->ev_fork, 0));
         // one pass over the page bytes; the two passes behind it only touch the chunks it gave up
-        if (pl->schain.str_stat) HIP_TRY(ctx, launch_str_fused(sst, src, pl->schain, pl->d_str_pd));
+        if (pl->schain.str_stat) HIP_TRY(ctx, launch_str_fused(sst, src, pl->schain, pl->d_str_pd, pl->ff_begin, pl->ff_bytes));
         HIP_TRY(ctx, launch_chain(sst, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_str_pd, pl->d_status, 0));
         HIP_TRY(ctx, launch_str_page_scan(sst, pl->d_sregions, pl->d_str_chunk_prefix, (u32)pl->str_chunk_prefix.size() - 1,
                                           pl->d_stotals, pl->d_str_pd, pl->schain.str_failed));

@@ -164,7 +164,8 @@ constexpr u32 SF_TPU = SF_WAVES * SF_TPW;      // tiles per unit
 constexpr u32 SF_REP_MAX = 2;                  // tiles of a unit that may be walked string by string
 static_assert(SF_TPU <= 64, "one lane per tile of a unit");
 constexpr u32 SF_STAMPS = 16;
-hipError_t launch_str_fused(hipStream_t st, const u8* src, const ChainArgs& a, PageDyn* str_pd);
+// ff_begin / ff_bytes: the entry tables of the two passes (a multiple of 16 bytes), set to 0xFF here when a chunk was given up
+hipError_t launch_str_fused(hipStream_t st, const u8* src, const ChainArgs& a, PageDyn* str_pd, u8* ff_begin, size_t ff_bytes);
 // otile_region: region of every expand tile plus one spare entry (may be null: the kernel then searches
 // otile_prefix); otile_first_run must have one spare entry after its n_otiles.
 hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Region* regions, const u32* otile_region,

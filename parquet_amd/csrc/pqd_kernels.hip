@@ -1509,6 +1509,14 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
 #undef SF_STAMP
 }
 
+// k_str_reset — behind k_str_fused: the entry tables of the two passes start from 0xFF.  They are only looked at when a
+// chunk was given up, so they are only filled then (a memset of the tables in front of every run moved 36 MB for nothing).
+__global__ __launch_bounds__(256) void k_str_reset(u32x4* __restrict__ p, size_t n16, const u32* __restrict__ any_failed) {
+    if (!*any_failed) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        p[i] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+}
+
 // k_str_totals — after k_str_fused, one thread per string page: the page's string count and its place in the chunk's
 // arrays, from the inclusive prefixes of the tiles at the page's borders (what k_chain_resolve and k_str_page_scan
 // leave on the two-pass path, which writes them itself for the chunks that were given up).
@@ -2826,7 +2834,7 @@ hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs
     return launch_chain_t<KIND_STRINGS>(st, src, a, run_tbl, otile_first_run, page_dyn, status, phase);
 }
 
-hipError_t launch_str_fused(hipStream_t st, const u8* src, const ChainArgs& a, PageDyn* str_pd) {
+hipError_t launch_str_fused(hipStream_t st, const u8* src, const ChainArgs& a, PageDyn* str_pd, u8* ff_begin, size_t ff_bytes) {
     if (a.n_regions == 0) return hipSuccess;
     if (a.n_units) {
         hipLaunchKernelGGL(k_str_fused, dim3(a.n_units), dim3(SF_THREADS), 0, st, src, a.regions, a.units,
@@ -2836,6 +2844,10 @@ hipError_t launch_str_fused(hipStream_t st, const u8* src, const ChainArgs& a, P
     hipLaunchKernelGGL(k_str_totals, dim3((a.n_regions + 63) / 64), dim3(64), 0, st, a.regions, a.n_regions, a.str_stat,
                        a.str_failed, a.totals, str_pd);
     LAUNCH_CHECK();
+    if (ff_bytes) {
+        hipLaunchKernelGGL(k_str_reset, dim3(1024), dim3(256), 0, st, (u32x4*)ff_begin, ff_bytes / 16, a.str_any);
+        LAUNCH_CHECK();
+    }
     return hipSuccess;
 }
 
