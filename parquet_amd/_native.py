@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-DECODE_PATH = os.path.join(LIB_DIR, "libpqdecode.so")
+DECODE_PATH = os.environ.get("PQD_LIB") or os.path.join(LIB_DIR, "libpqdecode.so")  # PQD_LIB: another build of the library (kernel experiments)
 SYNTH_PATH = os.path.join(LIB_DIR, "libpqsynth.so")
 
 # pqd_status

@@ -43,7 +43,7 @@ def build_all(force=False):
             objs.append(obj)
             deps = [src] + headers + (["pqd_levels.hip"] if src == "pqd_levels_4k.hip" else [])
             if force or _stale(obj, deps):
-                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
+                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("PQD_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
                 print("+", " ".join(cmd), flush=True)
                 jobs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
         for cmd, job in jobs:

@@ -549,8 +549,13 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         // are spread over all chunks and a unit's predecessors in its chunk are few and old
         const size_t nu = pl->sunit_region.size();
         pl->sunits.resize(nu);
-        std::vector<std::pair<u32, u32>> key(nu);
-        for (size_t u = 0; u < nu; u++) key[u] = {(u32)u - pl->sregions[pl->sunit_region[u]].lv_base, (u32)u};
+        std::vector<std::pair<u64, u32>> key(nu);
+        const char* gi = getenv("PQD_STR_INTERLEAVE");
+        const u32 G = gi && atoi(gi) > 0 ? (u32)atoi(gi) : 0xFFFFFFFFu;
+        for (size_t u = 0; u < nu; u++) {
+            const Region& R = pl->sregions[pl->sunit_region[u]];
+            key[u] = {(u64)(R.otile_base / G) << 32 | ((u32)u - R.lv_base), (u32)u};
+        }
         std::sort(key.begin(), key.end());
         for (size_t k = 0; k < nu; k++) {
             const u32 u = key[k].second, r = pl->sunit_region[u];

@@ -1113,6 +1113,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
 // still runs out (SF_TIMEOUT) gives the chunk up instead of hanging.
 // Nothing here reports corrupt data: a chunk that is given up gets its verdict from the two-pass kernels.
 // =====================================================================================
+#ifndef SF_EXP
+#define SF_EXP 0
+#endif
 constexpr u64 SF_AGG = 1, SF_INCL = 2, SF_FAIL = 3;  // state of a unit's status word (0: nothing published yet)
 constexpr u32 SF_PASS = 0xFFFFFFFDu;       // exit of a tile (unit) in which no string starts: the exit of the one before it
 constexpr u32 SF_CNT_MAX = (1u << 28) - 1; // strings of a chunk that the status word can count
@@ -1170,6 +1173,11 @@ static __device__ __forceinline__ u32 sf_small_mask(const u32 (&W)[9]) {
 // unit right in front of it.  False: the chunk was given up (by another unit, or here because the wait ran out).
 static __device__ __forceinline__ bool sf_lookback(const u64* __restrict__ ustat, u32 ui, u32 cf, u32 rf, const u32* chunk_failed,
                                                    u32 lane, u32& excl, u32& pexit, u32& pspill) {
+    // SF_LB blocks of 64 words are asked for per trip and gone through nearest first.  One block: with four, a batch of
+    // two chunks (a thousand units of each in flight, the nearest inclusive prefix 100-200 units back) was slower, not
+    // faster (0.76 against 0.64 ms): what a unit waits for there is the slowest of the units in front of it to publish
+    // at all, and four times the polling traffic on the same words made every trip longer.
+    constexpr int SF_LB = 1;
     excl = 0; pspill = 0;
     bool have_exit = ui == rf;
     pexit = 0;
@@ -1177,36 +1185,45 @@ static __device__ __forceinline__ bool sf_lookback(const u64* __restrict__ ustat
     long long base = ui;
     u64 t_start = 0;
     while (true) {
-        const long long j = base - 1 - (long long)lane;
-        const bool valid = j >= (long long)cf;
-        const u64 wd = valid ? sf_load(ustat + j) : sf_pack(SF_INCL, 0, 0, 0);  // in front of the chunk: an empty prefix
-        const u32 st = (u32)(wd >> 62);
-        const u64 m_incl = __ballot(st == SF_INCL), m_nr = __ballot(st == 0);
-        if (__ballot(st == SF_FAIL)) return false;
-        const u32 fi = m_incl ? (u32)__ffsll((unsigned long long)m_incl) - 1 : 64;
-        const u64 need = fi >= 63 ? ~0ull : (2ull << fi) - 1;  // lanes 0..fi
-        if (m_nr & need) {
+        u64 wds[SF_LB];
+#pragma unroll
+        for (int b = 0; b < SF_LB; b++) {
+            const long long j = base - 1 - 64 * b - (long long)lane;
+            wds[b] = j >= (long long)cf ? sf_load(ustat + j) : sf_pack(SF_INCL, 0, 0, 0);  // in front of the chunk: an empty prefix
+        }
+        bool again = false;
+#pragma unroll
+        for (int b = 0; b < SF_LB && !again; b++) {
+            const u64 wd = wds[b];
+            const long long j = base - 1 - (long long)lane;
+            const u32 st = (u32)(wd >> 62);
+            const u64 m_incl = __ballot(st == SF_INCL), m_nr = __ballot(st == 0);
+            if (__ballot(st == SF_FAIL)) return false;
+            const u32 fi = m_incl ? (u32)__ffsll((unsigned long long)m_incl) - 1 : 64;
+            const u64 need = fi >= 63 ? ~0ull : (2ull << fi) - 1;  // lanes 0..fi
+            if (m_nr & need) { again = true; break; }
+            if (!counted) excl += sf_wave_sum(lane <= fi ? (u32)(wd >> 32) & SF_CNT_MAX : 0);
+            if (first && ui > rf) pspill = (u32)((u64)__builtin_amdgcn_readfirstlane((int)(wd >> 32)) >> 28) & 3;  // lane 0: unit ui - 1, same page
+            first = false;
+            if (!have_exit) {
+                const u64 mc = __ballot(lane <= fi && j >= (long long)rf && (u32)wd != SF_PASS);
+                if (mc) {
+                    pexit = (u32)__shfl(wd, (int)__ffsll((unsigned long long)mc) - 1);
+                    have_exit = true;
+                }
+            }
+            if (fi < 64) counted = true;
+            if (counted && have_exit) return true;
+            base -= 64;
+            if (base <= (long long)cf && !have_exit) return false;  // cannot happen: a page's first unit has an exit
+        }
+        if (again) {
             if (__hip_atomic_load(chunk_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
             const u64 now = wall_clock64();
             if (!t_start) t_start = now;
             else if (now - t_start > SF_TIMEOUT) return false;
             __builtin_amdgcn_s_sleep(1);
-            continue;
         }
-        if (!counted) excl += sf_wave_sum(lane <= fi ? (u32)(wd >> 32) & SF_CNT_MAX : 0);
-        if (first && ui > rf) pspill = (u32)((u64)__builtin_amdgcn_readfirstlane((int)(wd >> 32)) >> 28) & 3;  // lane 0: unit ui - 1, same page
-        first = false;
-        if (!have_exit) {
-            const u64 mc = __ballot(lane <= fi && j >= (long long)rf && (u32)wd != SF_PASS);
-            if (mc) {
-                pexit = (u32)__shfl(wd, (int)__ffsll((unsigned long long)mc) - 1);
-                have_exit = true;
-            }
-        }
-        if (fi < 64) counted = true;
-        if (counted && have_exit) return true;
-        base -= 64;
-        if (base <= (long long)cf && !have_exit) return false;  // cannot happen: a page's first unit has an exit
     }
 }
 
@@ -1229,10 +1246,12 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
     // lie: the tiles are requested at once, the page's record comes beside them.
     const StrUnit U = units[blockIdx.x];
     const u32 ui = U.ui;
+    if (stamps && threadIdx.x == 0) { if (ui == 0xFFFFFFF0u) stamps[1] = 1; SF_STAMP(10); }
     const u32 n_on = (U.rem + CH_T - 1) / CH_T < SF_TPU ? (U.rem + CH_T - 1) / CH_T : SF_TPU;  // the unit's tiles (>= 1)
-    bool on[NT];
+    const Region R = regions[U.region];
+    bool on[NT], whole = true;
     u32 tb[NT], rem[NT], rlim[NT];
-    u32 w[NT][8];
+    u32 w[NT][8], nw[NT];  // the lane's 32 bytes of each tile and the four bytes behind them
 #pragma unroll
     for (u32 t = 0; t < NT; t++) {
         const u32 tu = wv * NT + t;
@@ -1240,24 +1259,64 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
         tb[t] = U.tb0 + tu * CH_T;                    // page position of the tile
         rem[t] = on[t] ? U.rem - tu * CH_T : 0;       // bytes from the tile's start to the end of the page
         rlim[t] = rem[t] < CH_T ? rem[t] : CH_T;      // bytes of the tile
-        if (on[t]) str_stage_tile(src_base + U.src_off + (u64)tu * CH_T, rem[t], 0, lane, w[t], s_buf[tu]);
+        whole = whole && rem[t] >= CH_T + 4;
     }
-    const Region R = regions[U.region];
+    if (whole) {
+        // every tile of the wave lies in the page with four bytes behind it: all of the wave's bytes are requested
+        // before the first of them is waited for (tile after tile, each staged before the next is asked for, the
+        // workgroup spent two to four trips to memory here instead of one)
+#pragma unroll
+        for (u32 t = 0; t < NT; t++) {
+            const u8* const p = src_base + U.src_off + (u64)(wv * NT + t) * CH_T + lane * CH_SUB;
+            const u32x4 a = *(const u32x4_u*)p, b = *(const u32x4_u*)(p + 16);
+            nw[t] = *(const u32_u*)(p + 32);
+            w[t][0] = a.x; w[t][1] = a.y; w[t][2] = a.z; w[t][3] = a.w; w[t][4] = b.x; w[t][5] = b.y; w[t][6] = b.z; w[t][7] = b.w;
+        }
+#pragma unroll
+        for (u32 t = 0; t < NT; t++) {
+            u32* const tl = s_buf[wv * NT + t];
+            *(u32x4*)(tl + lane * 8) = u32x4{w[t][0], w[t][1], w[t][2], w[t][3]};
+            *(u32x4*)(tl + lane * 8 + 4) = u32x4{w[t][4], w[t][5], w[t][6], w[t][7]};
+            if (lane == 63) { tl[CH_T / 4] = nw[t]; tl[CH_T / 4 + 1] = 0; }
+        }
+    } else {
+#pragma unroll
+        for (u32 t = 0; t < NT; t++)
+            if (on[t]) str_stage_tile(src_base + U.src_off + (u64)(wv * NT + t) * CH_T, rem[t], 0, lane, w[t], s_buf[wv * NT + t]);
+    }
     __builtin_amdgcn_wave_barrier();  // a wave reads only the tile images it wrote itself until the first barrier
+    if (!whole) {
+#pragma unroll
+        for (u32 t = 0; t < NT; t++) nw[t] = on[t] ? s_buf[wv * NT + t][lane * 8 + 8] : 0;  // the next lane's first word, or the lookahead
+    }
     if (stamps && threadIdx.x == 0) { if (s_buf[0][0] == 0x12345678u) stamps[0] = 1; SF_STAMP(1); }  // the read waits for the tile's bytes
 
     // ---- guess and proof inside each tile (positions relative to the tile)
-    u32 S[NT];
+    u32 S[NT], cmask[NT], incl[NT];
+    // From a tile's starts S: the lanes' char bytes (every byte of the tile that is no length byte; the bytes in front of
+    // its first start are the tail of the string that enters it) and the running sums of chars (low half) and starts
+    // (high half) over the lanes.  The up to three length bytes that spill in from the tile before are not known yet and
+    // count as chars here.
+    auto prep = [&](u32 t) {
+        const u32 smask = S[t];
+        u32 prev = __shfl_up(smask, 1);
+        if (lane == 0) prev = 0;
+        const u32 lenmask = smask | (smask << 1) | (smask << 2) | (smask << 3) | ((prev >> 29) & 1) | (((prev >> 30) & 1) * 3) |
+                            (((prev >> 31) & 1) * 7);
+        const u32 sub_lo = lane * CH_SUB;
+        const u32 k_hi = rlim[t] >= sub_lo + CH_SUB ? 32 : rlim[t] <= sub_lo ? 0 : rlim[t] - sub_lo;
+        const u32 own = k_hi >= 32 ? 0xFFFFFFFFu : (1u << k_hi) - 1;
+        cmask[t] = own & ~lenmask;
+        incl[t] = sf_wave_scan(__popc(cmask[t]) | (__popc(smask) << 16));
+    };
 #pragma unroll
     for (u32 t = 0; t < NT; t++) {
         const u32 tu = wv * NT + t;
         S[t] = 0;
         if (!on[t]) continue;
         const u32* const tl = s_buf[tu];
-        const u32 la = tl[CH_T / 4];  // the four bytes behind the tile
-        u32 nw = __shfl_down(w[t][0], 1);
-        if (lane == 63) nw = la;
-        const u32 W9[9] = {w[t][0], w[t][1], w[t][2], w[t][3], w[t][4], w[t][5], w[t][6], w[t][7], nw};
+        const u32 la = (u32)__builtin_amdgcn_readlane((int)nw[t], 63);  // the four bytes behind the tile
+        const u32 W9[9] = {w[t][0], w[t][1], w[t][2], w[t][3], w[t][4], w[t][5], w[t][6], w[t][7], nw[t]};
         u32 C;
         static_assert(STR_CAND_MAX == 1u << 20, "sf_small_mask tests for lengths below 2^20");
         if (rem[t] >= CH_T + 4 + STR_CAND_MAX) {  // every position of the tile has STR_CAND_MAX bytes of page behind it
@@ -1274,38 +1333,39 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
         u32 c_next = __shfl_down(C, 1) & 1;
         if (lane == 63) c_next = la < str_cand_room((int)rem[t] - 3 - (int)CH_T);
         const u32 Sm = C & ~((C >> 1) | (c_next << 31));
-        // the first guessed start in the lanes above mine, and of the tile
-        u32 v = Sm ? lane * CH_SUB + (u32)__ffs(Sm) - 1 : 0xFFFFu;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const u32 y = __shfl_down(v, d);
-            if (lane + d < 64) v = y < v ? y : v;
+        // the first guessed start in the lanes above mine (nf), and of the tile (ent): the lanes that hold a start, as a
+        // mask, say which lane to ask
+        const u64 has = __ballot(Sm != 0);
+        const u32 first = lane * CH_SUB + (u32)__ffs(Sm) - 1;
+        const u64 above = (has >> 1) >> lane;
+        const u32 nfl = __shfl(first, above ? (int)lane + (int)__ffsll((unsigned long long)above) : 0);
+        const u32 nf = above ? nfl : 0xFFFFu;
+        const u32 ent = has ? (u32)__builtin_amdgcn_readlane((int)first, __ffsll((unsigned long long)has) - 1) : 0xFFFFu;
+        // the proof inside the tile.  A start with another start behind it in the same lane: its end is that one (lanes
+        // with several starts go round together); the lane's last start: its end is the first start of the lanes above,
+        // or, for the tile's last start, lies at or beyond the tile's end (the tile's exit)
+        const u32 sub_lo = lane * CH_SUB;
+        u32 bad = 0, mi = Sm;
+        while (true) {
+            const u32 m2 = mi & (mi - 1);
+            if (!__any(m2 != 0)) break;
+            const u32 k = ((u32)__ffs(mi) - 1) & 31, k2 = (u32)__ffs(m2) - 1;
+            const u32 len = str_len_at(tl, sub_lo + k);
+            bad |= (u32)(m2 != 0) & (u32)(k + 4 + len != k2);
+            mi = m2 ? m2 : mi;
         }
-        u32 nf = __shfl_down(v, 1);
-        if (lane == 63) nf = 0xFFFFu;
-        const u32 ent = (u32)__builtin_amdgcn_readfirstlane((int)v);
-        bool good = true;
-        u32 my_exit = 0, my_last = 0xFFFFu, m = Sm;
-        while (__any(m != 0)) {
-            if (m) {
-                const u32 k = (u32)__ffs(m) - 1;
-                m &= m - 1;
-                const u32 p = lane * CH_SUB + k;
-                const u32 nx = p + 4 + str_len_at(tl, p);  // a candidate's length fits in the page
-                const u32 succ = m ? lane * CH_SUB + (u32)__ffs(m) - 1 : nf;
-                if (succ == 0xFFFFu) { good = good && nx >= rlim[t]; my_exit = nx; my_last = p; }
-                else good = good && nx == succ;
-            }
-        }
-        const bool ok = __all(good);
+        const u32 pl = sub_lo + ((31 - (u32)__clz((int)Sm)) & 31);  // the lane's last start (anything in a lane without one)
+        const u32 nxl = pl + 4 + str_len_at(tl, pl);               // a candidate's length fits in the page
+        bad |= (u32)(Sm != 0) & (u32)(above ? nxl != nf : nxl < rlim[t]);
+        const bool ok = !__any(bad != 0);
         S[t] = Sm;
-        const u32 cnt = sf_wave_sum(__popc(Sm));
-        const u64 bl = __ballot(my_last != 0xFFFFu);  // the lane of the tile's last start, if it has one
+        prep(t);
+        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)incl[t], 63) >> 16;
         u32 ext = SF_PASS, spill = 0;
-        if (bl) {
-            const int l = __ffsll((unsigned long long)bl) - 1;
-            ext = tb[t] + __shfl(my_exit, l);
-            const u32 lq = __shfl(my_last, l);
+        if (has) {
+            const int l = 63 - (int)__clzll((unsigned long long)has);  // the lane of the tile's last start
+            ext = tb[t] + (u32)__builtin_amdgcn_readlane((int)nxl, l);
+            const u32 lq = (u32)__builtin_amdgcn_readlane((int)pl, l);
             spill = lq + 4 > rlim[t] ? lq + 4 - rlim[t] : 0;
         }
         if (lane == 0) {
@@ -1329,28 +1389,36 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
     u32 n_chars[NT], a3[NT], ps[NT];
     auto compact = [&](u32 t, u32 spill_in) {
         const u32 tu = wv * NT + t;
-        const u32 smask = S[t];
-        u32 prev = __shfl_up(smask, 1);
-        if (lane == 0) prev = 0;
-        u32 lenmask = smask | (smask << 1) | (smask << 2) | (smask << 3) | ((prev >> 29) & 1) | (((prev >> 30) & 1) * 3) |
-                      (((prev >> 31) & 1) * 7);
-        if (lane == 0) lenmask |= (1u << spill_in) - 1;
-        const u32 sub_lo = lane * CH_SUB;
-        const u32 k_hi = rlim[t] >= sub_lo + CH_SUB ? 32 : rlim[t] <= sub_lo ? 0 : rlim[t] - sub_lo;
-        const u32 own = k_hi >= 32 ? 0xFFFFFFFFu : (1u << k_hi) - 1;
-        const u32 charmask = own & ~lenmask;
-        const u32 mine = __popc(charmask) | (__popc(smask) << 16);
-        const u32 incl = sf_wave_scan(mine);
-        n_chars[t] = (u32)__builtin_amdgcn_readlane((int)incl, 63) & 0xFFFF;
-        const u32 pc = (incl - mine) & 0xFFFF;
-        ps[t] = (incl - mine) >> 16;
+        const u32 charmask = lane == 0 ? cmask[t] & ~((1u << spill_in) - 1) : cmask[t];
+        const u32 excl = incl[t] - (__popc(cmask[t]) | (__popc(S[t]) << 16));
+        n_chars[t] = ((u32)__builtin_amdgcn_readlane((int)incl[t], 63) & 0xFFFF) - spill_in;
+        const u32 pc = lane == 0 ? 0 : (excl & 0xFFFF) - spill_in;
+        ps[t] = excl >> 16;
         // the chars keep their place within a 4-byte word of the destination whatever the rank turns out to be (it moves
         // them by a multiple of 4): byte i of the tile's chars goes to byte a3 + i of the image
         a3[t] = (u32)((uintptr_t)R.out2 + R.run_base + tb[t] + spill_in) & 3;
         u8* const stage = (u8*)s_buf[tu];  // every read of the tile image is over
+        // from the lane's last byte down: shifting the mask out at the top gives the byte's bit as a carry, which both
+        // moves the address down by one and decides the store (two instructions a byte)
+        u32 mk = charmask;
+        u8* ap = stage + (a3[t] + pc + __popc(charmask));
 #pragma unroll
-        for (int k = 0; k < (int)CH_SUB; k++)
-            if ((charmask >> k) & 1) stage[a3[t] + pc + __popc(charmask & ((1u << k) - 1))] = (u8)(w[t][k >> 2] >> (8 * (k & 3)));
+        for (int k = (int)CH_SUB - 1; k >= 0; k--) {
+            const bool c = __builtin_add_overflow(mk, mk, &mk);
+            ap -= c;
+            const u32 x = (k & 1) ? w[t][k >> 2] >> 8 : w[t][k >> 2];  // bytes 1 and 3 of a word share one shift
+            if (c && !(SF_EXP & 4)) *ap = (u8)((k & 2) ? x >> 16 : x);
+        }
+        // The tile's offsets, less what the rank adds, go into the words of the image behind the chars: every start took
+        // four length bytes out of the chars, so there is room for exactly its offset (at most a3 + spill + alignment =
+        // 9 bytes more than the tile, and the image has 16).  From there they are stored in rank order, lane by lane.
+        u32* const ow = s_buf[tu] + ((a3[t] + n_chars[t] + 3) >> 2) + ps[t];
+        u32 m = S[t], v = lane * CH_SUB - 4 * ps[t], j = 0;
+        while (m) {
+            ow[j++] = v + (u32)__ffs(m) - 1;
+            m &= m - 1;
+            v -= 4;
+        }
     };
 
     // ---- the unit: ranks, the proof between tiles, repairs (wave 0), while the other waves compact their chars
@@ -1459,7 +1527,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
         for (u32 t = 0; t < NT; t++) {
             const u32 tu = wv * NT + t;
             if (!on[t]) continue;
-            if (s_slot[tu] != BAD) S[t] = s_bits[s_slot[tu]][lane];
+            if (s_slot[tu] != BAD) { S[t] = s_bits[s_slot[tu]][lane]; prep(t); }
             compact(t, tu == 0 ? s_spin0 : s_spill[tu - 1]);
         }
     }
@@ -1480,17 +1548,16 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
             continue;
         }
         {
-            int32_t* const offs = (int32_t*)R.out;
-            const u32 cap = R.width;  // entries of the chunk's offsets array in front of the closing one
-            const u32 sbase = (u32)R.run_base + tb[t] + lane * CH_SUB;
-            u32 m = S[t], rank = excl + ps[t];
-            while (m) {
-                const u32 k = __ffs(m) - 1;
-                m &= m - 1;
-                if (rank < cap) offs[rank] = (int32_t)(sbase + k - 4u * rank);
-                rank++;
-            }
+            int32_t* const offs = (int32_t*)R.out + excl;
+            const u32 cap = R.width > excl ? R.width - excl : 0;  // entries of the chunk's offsets array in front of the closing one
+            const u32 cnt = (u32)__builtin_amdgcn_readlane((int)incl[t], 63) >> 16;
+            const u32 n = cnt < cap ? cnt : cap;
+            const u32* const ow = s_buf[tu] + ((a3[t] + n_chars[t] + 3) >> 2);
+            const u32 add = (u32)R.run_base + tb[t] - 4u * excl;
+            for (u32 i = lane; i < n; i += 64)
+                if (!(SF_EXP & 1)) offs[i] = (int32_t)(ow[i] + add);
         }
+        SF_STAMP(11 + 2 * t);
         u8* const cd = R.out2 + (q0 - 4ull * excl);
         const u32 pd0 = (u32)((uintptr_t)cd & 15), shift = pd0 - a3[t];  // pd0 % 4 == a3: the image is `shift` bytes (0, 4, 8, 12) ahead
         const u8* const stage = (const u8*)s_buf[tu] - shift;              // stage[pd0 + i] = byte i of the tile's chars
@@ -1500,10 +1567,11 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
         const u32 tail_lo = (n_stg & ~15u) > head_end ? (n_stg & ~15u) : head_end;
         for (u32 c0 = head_end + lane * 16; c0 < tail_lo; c0 += 64 * 16) {
             const u32* const sp = (const u32*)(stage + c0);  // 4-byte aligned
-            *(u32x4*)(cd - pd0 + c0) = u32x4{sp[0], sp[1], sp[2], sp[3]};
+            if (!(SF_EXP & 2)) *(u32x4*)(cd - pd0 + c0) = u32x4{sp[0], sp[1], sp[2], sp[3]};
         }
         if (lane < 16) { if (pd0 + lane < head_end) cd[lane] = stage[pd0 + lane]; }
         else if (lane < 32) { const u32 b = tail_lo + lane - 16; if (b < n_stg) cd[b - pd0] = stage[b]; }
+        SF_STAMP(12 + 2 * t);
     }
     SF_STAMP(9);
 #undef SF_STAMP
