@@ -79,14 +79,14 @@ __global__ __launch_bounds__(CP_THREADS) void k_copy(const u8* __restrict__ src_
 #pragma unroll
             for (int i = 0; i < CP_UNROLL; i++) {
                 const u32 k = tid + i * CP_THREADS;
-                if (k < n_units) __builtin_nontemporal_store(r[i], (u32x4*)(dv + u0 + (u64)k * 16));
+                if (k < n_units) __builtin_nontemporal_store(r[i], as_global((u32x4*)(dv + u0 + (u64)k * 16)));
             }
             // head [v_lo, u0) and tail [u1, v_hi): fewer than 16 bytes each
-            if (tid < (u32)(u0 - v_lo)) dv[v_lo + tid] = sv[v_lo + tid];
-            if (tid < (u32)(v_hi - u1)) dv[u1 + tid] = sv[u1 + tid];
+            if (tid < (u32)(u0 - v_lo)) *as_global(dv + v_lo + tid) = sv[v_lo + tid];
+            if (tid < (u32)(v_hi - u1)) *as_global(dv + u1 + tid) = sv[u1 + tid];
         } else {
             // fewer than 31 bytes in total
-            if (tid < (u32)(v_hi - v_lo)) dv[v_lo + tid] = sv[v_lo + tid];
+            if (tid < (u32)(v_hi - v_lo)) *as_global(dv + v_lo + tid) = sv[v_lo + tid];
         }
     }
 }
@@ -1235,6 +1235,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
     constexpr u32 BAD = 0xFFFFFFFFu;  // s_cnt of a tile whose guess did not prove itself
 #define SF_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(u64)blockIdx.x * SF_STAMPS + (i)] = wall_clock64(); } while (0)
     SF_STAMP(0);
+    const u64 cyc0 = stamps ? (u64)clock64() : 0;
     __shared__ __attribute__((aligned(16))) u32 s_buf[SF_TPU][STR_LDS_WORDS];
     __shared__ u32 s_cnt[SF_TPU], s_ent[SF_TPU], s_ext[SF_TPU], s_spill[SF_TPU], s_excl[SF_TPU], s_slot[SF_TPU];
     __shared__ u32 s_bits[SF_REP_MAX][64];
@@ -1383,20 +1384,21 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
 
     // ---- offsets and chars of a tile, in two steps.  Every byte of a tile that is no length byte is a char (the bytes in
     // front of its first start are the tail of the string that enters it), so a tile moves exactly its own bytes.
-    // Step 1 needs the tile's starts and the spill of the tile before it, nothing from other units: the chars are compacted
-    // into the tile's LDS image.  Step 2 needs the rank of the tile's first string: string number g at stream position q
-    // has its chars at q - 4 g, so the tile's chars go to (stream position of the tile) + spill - 4 (strings before it).
-    u32 n_chars[NT], a3[NT], ps[NT];
-    auto compact = [&](u32 t, u32 spill_in) {
+    // Step 1 needs the tile's starts and nothing from other tiles: the chars are compacted into the tile's LDS image (the
+    // up to three length bytes that spill in from the tile before still count as chars and lead them).  Step 2 needs the
+    // spill and the rank of the tile's first string: string number g at stream position q has its chars at q - 4 g, so
+    // the tile's chars go to (stream position of the tile) + spill - 4 (strings before it).
+    u32 n_all[NT], a3[NT], ps[NT];
+    auto compact = [&](u32 t) {
         const u32 tu = wv * NT + t;
-        const u32 charmask = lane == 0 ? cmask[t] & ~((1u << spill_in) - 1) : cmask[t];
+        const u32 charmask = cmask[t];
         const u32 excl = incl[t] - (__popc(cmask[t]) | (__popc(S[t]) << 16));
-        n_chars[t] = ((u32)__builtin_amdgcn_readlane((int)incl[t], 63) & 0xFFFF) - spill_in;
-        const u32 pc = lane == 0 ? 0 : (excl & 0xFFFF) - spill_in;
+        n_all[t] = (u32)__builtin_amdgcn_readlane((int)incl[t], 63) & 0xFFFF;
+        const u32 pc = excl & 0xFFFF;
         ps[t] = excl >> 16;
         // the chars keep their place within a 4-byte word of the destination whatever the rank turns out to be (it moves
-        // them by a multiple of 4): byte i of the tile's chars goes to byte a3 + i of the image
-        a3[t] = (u32)((uintptr_t)R.out2 + R.run_base + tb[t] + spill_in) & 3;
+        // them by a multiple of 4): byte i of the tile that is no length byte goes to byte a3 + i of the image
+        a3[t] = (u32)((uintptr_t)R.out2 + R.run_base + tb[t]) & 3;
         u8* const stage = (u8*)s_buf[tu];  // every read of the tile image is over
         // from the lane's last byte down: shifting the mask out at the top gives the byte's bit as a carry, which both
         // moves the address down by one and decides the store (two instructions a byte)
@@ -1412,7 +1414,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
         // The tile's offsets, less what the rank adds, go into the words of the image behind the chars: every start took
         // four length bytes out of the chars, so there is room for exactly its offset (at most a3 + spill + alignment =
         // 9 bytes more than the tile, and the image has 16).  From there they are stored in rank order, lane by lane.
-        u32* const ow = s_buf[tu] + ((a3[t] + n_chars[t] + 3) >> 2) + ps[t];
+        u32* const ow = s_buf[tu] + ((a3[t] + n_all[t] + 3) >> 2) + ps[t];
         u32 m = S[t], v = lane * CH_SUB - 4 * ps[t], j = 0;
         while (m) {
             ow[j++] = v + (u32)__ffs(m) - 1;
@@ -1436,6 +1438,10 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
             tot = sf_wave_sum(c);
             if (m_ex) uexit = __shfl(e, 63 - (int)__clzll((unsigned long long)m_ex));
             if (lane == 0) sf_store(ustat + ui, sf_pack(SF_AGG, uspill0, tot, uexit));
+            // its own tiles before it looks back: the units in front need the time anyway
+#pragma unroll
+            for (u32 t = 0; t < NT; t++)
+                if (on[t]) compact(t);
         }
         u32 uexcl = 0, pexit = 0, pspill = 0;
         SF_STAMP(4);
@@ -1509,15 +1515,10 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
         }
         if (lane == 0) s_alive = alive;
         SF_STAMP(6);
-        if (alive && all_ok) {
-#pragma unroll
-            for (u32 t = 0; t < NT; t++)
-                if (on[t]) compact(t, t == 0 ? pspill : s_spill[t - 1]);
-        }
     } else if (all_ok) {
 #pragma unroll
         for (u32 t = 0; t < NT; t++)
-            if (on[t]) compact(t, s_spill[wv * NT + t - 1]);
+            if (on[t]) compact(t);
     }
     __syncthreads();
     if (!s_alive) return;
@@ -1528,7 +1529,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
             const u32 tu = wv * NT + t;
             if (!on[t]) continue;
             if (s_slot[tu] != BAD) { S[t] = s_bits[s_slot[tu]][lane]; prep(t); }
-            compact(t, tu == 0 ? s_spin0 : s_spill[tu - 1]);
+            compact(t);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1552,28 +1553,32 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
             const u32 cap = R.width > excl ? R.width - excl : 0;  // entries of the chunk's offsets array in front of the closing one
             const u32 cnt = (u32)__builtin_amdgcn_readlane((int)incl[t], 63) >> 16;
             const u32 n = cnt < cap ? cnt : cap;
-            const u32* const ow = s_buf[tu] + ((a3[t] + n_chars[t] + 3) >> 2);
+            const u32* const ow = s_buf[tu] + ((a3[t] + n_all[t] + 3) >> 2);
             const u32 add = (u32)R.run_base + tb[t] - 4u * excl;
+#pragma unroll 1
             for (u32 i = lane; i < n; i += 64)
-                if (!(SF_EXP & 1)) offs[i] = (int32_t)(ow[i] + add);
+                if (!(SF_EXP & 1)) *as_global(offs + i) = (int32_t)(ow[i] + add);
         }
         SF_STAMP(11 + 2 * t);
         u8* const cd = R.out2 + (q0 - 4ull * excl);
-        const u32 pd0 = (u32)((uintptr_t)cd & 15), shift = pd0 - a3[t];  // pd0 % 4 == a3: the image is `shift` bytes (0, 4, 8, 12) ahead
-        const u8* const stage = (const u8*)s_buf[tu] - shift;              // stage[pd0 + i] = byte i of the tile's chars
-        const u32 n_stg = pd0 + n_chars[t];
+        // byte i of the tile's chars is byte a3 + spin + i of the image and goes to cd + i; pd0 % 4 == (a3 + spin) % 4
+        const u32 pd0 = (u32)((uintptr_t)cd & 15);
+        const int shift = (int)pd0 - (int)(a3[t] + spin);              // a multiple of 4 between -4 and 12
+        const u8* const stage = (const u8*)s_buf[tu] - shift;          // stage[pd0 + i] = byte i of the tile's chars
+        const u32 n_stg = pd0 + n_all[t] - spin;
         // aligned 16-byte stores between the first and the last 16-byte boundary; the up to 15 bytes on either side go one per lane
         const u32 head_end = ((pd0 + 15) & ~15u) < n_stg ? ((pd0 + 15) & ~15u) : n_stg;
         const u32 tail_lo = (n_stg & ~15u) > head_end ? (n_stg & ~15u) : head_end;
         for (u32 c0 = head_end + lane * 16; c0 < tail_lo; c0 += 64 * 16) {
             const u32* const sp = (const u32*)(stage + c0);  // 4-byte aligned
-            if (!(SF_EXP & 2)) *(u32x4*)(cd - pd0 + c0) = u32x4{sp[0], sp[1], sp[2], sp[3]};
+            if (!(SF_EXP & 2)) *as_global((u32x4*)(cd - pd0 + c0)) = u32x4{sp[0], sp[1], sp[2], sp[3]};
         }
-        if (lane < 16) { if (pd0 + lane < head_end) cd[lane] = stage[pd0 + lane]; }
-        else if (lane < 32) { const u32 b = tail_lo + lane - 16; if (b < n_stg) cd[b - pd0] = stage[b]; }
+        if (lane < 16) { if (pd0 + lane < head_end) *as_global(cd + lane) = stage[pd0 + lane]; }
+        else if (lane < 32) { const u32 b = tail_lo + lane - 16; if (b < n_stg) *as_global(cd + (b - pd0)) = stage[b]; }
         SF_STAMP(12 + 2 * t);
     }
     SF_STAMP(9);
+    if (stamps && threadIdx.x == 0) stamps[(u64)blockIdx.x * SF_STAMPS + 15] = (u64)clock64() - cyc0;
 #undef SF_STAMP
 }
 
@@ -2725,18 +2730,16 @@ __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunk
     if (i0 < n) {
         const u32 in_range = n - i0 >= 16 ? 0xFFFFu : (1u << (n - i0)) - 1;
         // the level decode left both as bitmaps (16 levels = one 16-bit word; the arrays are padded)
-        valid = ((const unsigned short*)C.validity)[i0 >> 4] & in_range;
-        starts = ((const unsigned short*)C.row_starts)[i0 >> 4] & in_range;
+        valid = as_global((const unsigned short*)C.validity)[i0 >> 4] & in_range;
+        starts = as_global((const unsigned short*)C.row_starts)[i0 >> 4] & in_range;
         if (i0 == 0) starts |= 1;  // the first level opens a row whatever its rep level (write_repeated.go:62-80)
     }
-    // block-wide exclusive scan of (row starts, valid)
+    // block-wide exclusive scan of (row starts, valid): a wave holds 1024 levels, so both sums fit in one half word each
+    // and go through one scan
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    u32 r = __popc(starts), v = __popc(valid);
-    u32 sr = r, sv = v;
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 tr = __shfl_up(sr, d), tv = __shfl_up(sv, d);
-        if (lane >= (u32)d) { sr += tr; sv += tv; }
-    }
+    const u32 r = __popc(starts), v = __popc(valid);
+    const u32 both = sf_wave_scan(r | v << 16);
+    const u32 sr = both & 0xFFFF, sv = both >> 16;
     if (lane == 63) { s_rows[wv] = sr; s_vals[wv] = sv; }
     __syncthreads();
     u32 br = 0, bv = 0, tot_r = 0, tot_v = 0;
@@ -2768,11 +2771,11 @@ __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunk
     int32_t* rl = (int32_t*)C.row_level_off + T.row_base;
     int32_t* rv = (int32_t*)C.row_value_off + T.row_base;
     if (C.shares_rep) {  // the level offsets are the twin chunk's
-        for (u32 j = threadIdx.x; j < tot_r; j += 256) rv[j] = (int32_t)(T.val_base + s_rv[j]);
+        for (u32 j = threadIdx.x; j < tot_r; j += 256) *as_global(rv + j) = (int32_t)(T.val_base + s_rv[j]);
     } else {
         for (u32 j = threadIdx.x; j < tot_r; j += 256) {
-            rl[j] = (int32_t)(lvl0 + s_rl[j]);
-            rv[j] = (int32_t)(T.val_base + s_rv[j]);
+            *as_global(rl + j) = (int32_t)(lvl0 + s_rl[j]);
+            *as_global(rv + j) = (int32_t)(T.val_base + s_rv[j]);
         }
     }
 }

@@ -780,8 +780,8 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
             } else v = lv_dense16(dense, (u32)((int)LV_DENSE_BIAS + ((int)v0 - (int)mis) * (int)width), width);
             u8* const dst = dbase + v0;
             const u64 acc_lo = v.x | ((u64)v.y << 32), acc_hi = v.z | ((u64)v.w << 32);
-            if (hi_v - lo_v == 16) *(u32x4*)dst = v;
-            else for (u32 k = lo_v - v0; k < hi_v - v0; k++) dst[k] = (u8)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8)));
+            if (hi_v - lo_v == 16) *as_global((u32x4*)dst) = v;
+            else for (u32 k = lo_v - v0; k < hi_v - v0; k++) *as_global(dst + k) = (u8)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8)));
             if (counting) {
                 // bit k: value k of the block equals max_def (fields.go:220-228); bits [k0, k1) are mine
                 const u32 k0 = lo_v - v0, k1 = hi_v - v0;
@@ -790,8 +790,8 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
                 cnt += __popc(mine);
                 if (vbits) {
                     const u64 li = R.run_base + g_lo + v0 - mis;  // chunk level index of the block's first value: a multiple of 16
-                    if (k1 - k0 == 16) ((unsigned short*)vbits)[li >> 4] = (unsigned short)mine;
-                    else if (mine) atomicOr((u32*)vbits + (li >> 5), mine << (li & 16));  // a block shared with another workgroup or page
+                    if (k1 - k0 == 16) *as_global((unsigned short*)vbits + (li >> 4)) = (unsigned short)mine;
+                    else if (mine) __hip_atomic_fetch_or(as_global((u32*)vbits + (li >> 5)), mine << (li & 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a block shared with another workgroup or page
                 }
             }
         }

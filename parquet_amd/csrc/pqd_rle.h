@@ -10,6 +10,12 @@ namespace pqd {
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));
+// A pointer that was read from a table in memory is a generic one to the compiler, and stores through it become FLAT
+// instructions (checked against the LDS aperture, counted on the LDS counter as well, so that LDS reads behind them
+// wait for them).  Output arrays always lie in device memory: as_global says so.
+#define PQD_GLOBAL __attribute__((address_space(1)))
+template <class T>
+static __device__ __forceinline__ PQD_GLOBAL T* as_global(T* p) { return (PQD_GLOBAL T*)p; }
 typedef u64 u64_u __attribute__((aligned(1)));
 typedef u32 u32_u __attribute__((aligned(1)));
 
