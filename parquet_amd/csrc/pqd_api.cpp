@@ -25,6 +25,7 @@ struct pqd_ctx {
     bool str_fused = true;          // PQD_STR_PATH=twopass: every string chunk through the two passes (the single pass's fallback)
     bool str_giveup = false;        // PQD_STR_PATH=giveup: the single pass runs but finds every chunk given up already (tests of the hand-over)
     bool graph = false;             // PQD_GRAPH=1 replays chain batches as a captured HIP graph
+    bool rows_first = true;         // PQD_ROWS_FIRST=0: the row offsets behind the value index, as they once were
     std::string err;
     u32 copy_grid = 0x7fffffffu;  // one block per 4 KiB tile; PQD_COPY_GRID caps it (then blocks grid-stride)
 };
@@ -156,10 +157,18 @@ int pqd_create(int device, pqd_ctx** out) {
     if (e != hipSuccess || device < 0 || device >= n) return PQD_E_HIP;
     pqd_ctx* ctx = new pqd_ctx();
     ctx->device = device;
+    // Stream priorities (PQD_PRIO=main,strings,gather; smaller = more urgent, clamped to what the device offers): the main
+    // stream carries the chain of short kernels behind the level decode, which must not queue behind the hundred thousand
+    // workgroups of the string pass and of the gather, or they run alone at the end of the batch.
+    int prio[3] = {-1, 0, 1};
+    if (const char* pr = getenv("PQD_PRIO")) (void)sscanf(pr, "%d,%d,%d", &prio[0], &prio[1], &prio[2]);
+    int p_least = 0, p_greatest = 0;
+    if (hipSetDevice(device) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&p_least, &p_greatest);
+    for (int& q : prio) q = q < p_greatest ? p_greatest : q > p_least ? p_least : q;
     if (hipSetDevice(device) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio[0]) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio[1]) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, prio[2]) != hipSuccess) {
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
         delete ctx;
@@ -184,6 +193,8 @@ int pqd_create(int device, pqd_ctx** out) {
     if (sp) ctx->str_giveup = strcmp(sp, "giveup") == 0;
     const char* gr = getenv("PQD_GRAPH");
     if (gr) ctx->graph = atoi(gr) != 0;
+    const char* rf = getenv("PQD_ROWS_FIRST");
+    if (rf) ctx->rows_first = atoi(rf) != 0;
     *out = ctx;
     return PQD_OK;
 }
@@ -814,6 +825,10 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
 
     // levels, then everything that only needs them
     if (n_lreg) HIP_TRY(ctx, launch_levels(st, src, pl->lv, pl->lv_tile));
+    // the row offsets need the bitmaps of the level decode and nothing else: the longest kernel of this stream goes first
+    if (ctx->rows_first)
+        HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_rtile_owner, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
+                                 pl->d_row_tiles, pl->d_chunk_dyn));
     HIP_TRY(ctx, launch_page_scan(st, pl->d_chunks, n_chunks, pl->d_pages, n_pages, pl->d_page_dyn, pl->d_chunk_dyn, pl->d_status));
     if (n_sreg) {
         if (str_early && ctx->str_after_levels) {  // diagnostics: the marking pass behind the level decode, as it was when it took the page offsets from there
@@ -835,8 +850,9 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     if (vidx_side) HIP_TRY(ctx, hipEventRecord(pl->ev_join, ctx->stream2));
     HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, pl->d_btile_owner, (u32)pl->bool_pages.size(), pl->n_btiles,
                               pl->d_chunks, pl->d_page_dyn, pl->d_status));
-    HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_rtile_owner, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
-                             pl->d_row_tiles, pl->d_chunk_dyn));
+    if (!ctx->rows_first)
+        HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_rtile_owner, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
+                                 pl->d_row_tiles, pl->d_chunk_dyn));
     if (n_sreg) {
         if (str_early) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join, 0));
         HIP_TRY(ctx, launch_str_check(st, pl->d_pages, pl->d_chunks, pl->d_page_dyn, pl->d_sregions, n_sreg, pl->d_stotals, pl->d_status));

@@ -1286,6 +1286,10 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
             if (on[t]) str_stage_tile(src_base + U.src_off + (u64)(wv * NT + t) * CH_T, rem[t], 0, lane, w[t], s_buf[wv * NT + t]);
     }
     __builtin_amdgcn_wave_barrier();  // a wave reads only the tile images it wrote itself until the first barrier
+    // every load of the wave has arrived (its bytes are in the image).  Said out loud: the compiler does not see it on every
+    // path, and a wait for loads that it puts further down also waits for the stores in flight by then (the status words,
+    // the tile before), a trip to memory each time.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     if (!whole) {
 #pragma unroll
         for (u32 t = 0; t < NT; t++) nw[t] = on[t] ? s_buf[wv * NT + t][lane * 8 + 8] : 0;  // the next lane's first word, or the lookahead
