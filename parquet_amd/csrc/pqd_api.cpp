@@ -513,7 +513,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
                 R.count_level = (u32)pl->sunit_region.size();  // first unit of the page
                 R.lv_base = str_chunk_unit0;                    // first unit of the chunk
                 R.run_base = val_stream_off[pi];
-                pl->sunit_region.insert(pl->sunit_region.end(), ((size_t)P.val_len + SF_TPU * CH_T - 1) / (SF_TPU * CH_T), (u32)pl->sregions.size());
+                pl->sunit_region.insert(pl->sunit_region.end(), ((size_t)P.val_len + SF_UNIT - 1) / SF_UNIT, (u32)pl->sregions.size());
                 R.width = (u32)(C.n_levels < 0xFFFFFFFFull ? C.n_levels : 0xFFFFFFFFull);
                 R.otile_base = (u32)pl->str_chunk_prefix.size() - 1;
                 pl->sregions.push_back(R);
@@ -571,7 +571,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         for (size_t k = 0; k < nu; k++) {
             const u32 u = key[k].second, r = pl->sunit_region[u];
             const Region& R = pl->sregions[r];
-            const u32 tb0 = (u - R.count_level) * SF_TPU * CH_T;
+            const u32 tb0 = (u - R.count_level) * SF_UNIT;
             pl->sunits[k] = StrUnit{R.src_off + tb0, tb0, R.len - tb0, r, u};
         }
     }

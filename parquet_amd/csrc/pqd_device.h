@@ -119,7 +119,7 @@ struct StrIndex {
     unsigned short* gpre;        // n_tiles: plausible positions in the earlier tiles of the tile's group (k_chain_groups)
     unsigned short* spre;        // n_tiles: ... of the tile's super-group (k_chain_supers)
 };
-// strings, single pass: SF_TPU tiles of one page, decoded by one workgroup
+// strings, single pass: SF_UNIT bytes of one page, decoded by one workgroup
 struct StrUnit {
     u64 src_off;  // source offset of the unit's first byte
     u32 tb0;      // page position of that byte
@@ -146,7 +146,7 @@ struct ChainArgs {
     StrIndex str_index;       // strings only (written by pass 1)
     // strings, single pass (k_str_fused): null = the two passes decode every chunk
     u64* str_stat;            // n_units status words {state, strings, exit}; zero before every run
-    u32 n_units;              // units of SF_TPU tiles of one page
+    u32 n_units;              // units of SF_UNIT bytes of one page
     const StrUnit* units;     // n_units, in launch order: the k-th unit of every chunk before the k+1-th of any
     u64* str_stamps;          // diagnostics only (else null): SF_STAMPS wall-clock stamps (100 MHz) per workgroup of k_str_fused
     u32* str_failed;          // one word per BYTE_ARRAY chunk, zero before every run: set = the chunk goes through the two passes
@@ -159,8 +159,11 @@ hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs
 // Region fields on this path: count_level = first unit of the region, lv_base = first unit of the region's chunk,
 // run_base = bytes of the chunk's earlier pages (values regions), width = entries of the chunk's offsets array,
 // otile_base = index of the chunk among the BYTE_ARRAY chunks.
-constexpr u32 SF_WAVES = 4, SF_TPW = 2;        // waves per workgroup (unit), tiles per wave
-constexpr u32 SF_TPU = SF_WAVES * SF_TPW;      // tiles per unit
+constexpr u32 SF_WAVES = 4;                    // waves per workgroup (unit)
+constexpr u32 SF_SUB = 64, SF_T = 64 * SF_SUB; // bytes per lane and per tile of this kernel (a tile is one wave's)
+constexpr u32 SF_TPU = SF_WAVES;               // tiles per unit
+constexpr u32 SF_UNIT = SF_TPU * SF_T;         // bytes per unit
+constexpr u32 SF_LDS_WORDS = SF_T / 4 + 4;     // a tile's image in LDS: its bytes, four bytes of lookahead, room for the staged offsets
 constexpr u32 SF_REP_MAX = 2;                  // tiles of a unit that may be walked string by string
 static_assert(SF_TPU <= 64, "one lane per tile of a unit");
 constexpr u32 SF_STAMPS = 16;

@@ -1227,20 +1227,51 @@ static __device__ __forceinline__ bool sf_lookback(const u64* __restrict__ ustat
     }
 }
 
+// value of the lane above / below (0 where there is none): one DPP move, no trip through the LDS crossbar
+static __device__ __forceinline__ u32 sf_lane_above(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }  // wave_shl:1
+static __device__ __forceinline__ u32 sf_lane_below(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }  // wave_shr:1
+
+// loads the lane's SF_SUB bytes of a tile that ends inside its page, or within four bytes of the page's end (bytes at or
+// past L read as zero), into w and into the LDS image, with the four bytes behind the tile
+static __device__ __forceinline__ void sf_stage_tail(const u8* rsrc, u32 L, u32 lane, u32 (&w)[SF_SUB / 4], u32* s_tile) {
+    auto word_at = [&](u32 p) -> u32 {
+        u32 v = 0;
+        if (p < L) {
+            if (L - p >= 4) v = *(const u32_u*)(rsrc + p);
+            else for (u32 k = 0; k < L - p; k++) v |= (u32)rsrc[p + k] << (8 * k);
+        }
+        return v;
+    };
+#pragma unroll
+    for (u32 d = 0; d < SF_SUB / 4; d++) {
+        w[d] = word_at(lane * SF_SUB + 4 * d);
+        s_tile[lane * (SF_SUB / 4) + d] = w[d];
+    }
+    if (lane == 0) {
+        s_tile[SF_T / 4] = word_at(SF_T);  // a length prefix may start in the last 3 bytes of the tile
+        s_tile[SF_T / 4 + 1] = 0;
+    }
+}
+
+// One workgroup = one unit = SF_TPU tiles of SF_T bytes, a tile per wave, SF_SUB = 64 bytes per lane: what is done once per
+// tile (the hand-over between lanes, the scan, the bookkeeping of ranks and exits, the set-up of the stores) is a third
+// of the instructions, and this kernel is bound by instruction issue.
 __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                           const StrUnit* __restrict__ units,
                                                           u64* __restrict__ ustat, u32* __restrict__ chunk_failed,
                                                           u32* __restrict__ any_failed, u64* __restrict__ stamps) {
-    constexpr u32 NT = SF_TPW;
     constexpr u32 BAD = 0xFFFFFFFFu;  // s_cnt of a tile whose guess did not prove itself
+    constexpr u32 NW = SF_SUB / 4;    // words per lane
+    constexpr u32 NONE = 0xFFFFu;     // no start (positions are below SF_T + 4 + STR_CAND_MAX only where compared with this)
+    static_assert(SF_SUB == 64 && SF_TPU == SF_WAVES, "one 64-bit mask per lane, one tile per wave");
 #define SF_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(u64)blockIdx.x * SF_STAMPS + (i)] = wall_clock64(); } while (0)
     SF_STAMP(0);
     const u64 cyc0 = stamps ? (u64)clock64() : 0;
-    __shared__ __attribute__((aligned(16))) u32 s_buf[SF_TPU][STR_LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) u32 s_buf[SF_TPU][SF_LDS_WORDS];
     __shared__ u32 s_cnt[SF_TPU], s_ent[SF_TPU], s_ext[SF_TPU], s_spill[SF_TPU], s_excl[SF_TPU], s_slot[SF_TPU];
-    __shared__ u32 s_bits[SF_REP_MAX][64];
+    __shared__ u32 s_bits[SF_REP_MAX][SF_T / 32];
     __shared__ u32 s_alive, s_spin0;
-    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u32 lane = threadIdx.x & 63, tu = threadIdx.x >> 6;  // the wave's tile of the unit
     // Workgroup b takes unit b of the launch order (a workgroup that took several units in turn, with the next unit's bytes
     // requested ahead, was tried: whatever hands the units out, one shared counter, eight of them or a fixed stride,
     // costs more in waits for units in front than the requests ahead save).  One table entry says where the unit's bytes
@@ -1248,134 +1279,118 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
     const StrUnit U = units[blockIdx.x];
     const u32 ui = U.ui;
     if (stamps && threadIdx.x == 0) { if (ui == 0xFFFFFFF0u) stamps[1] = 1; SF_STAMP(10); }
-    const u32 n_on = (U.rem + CH_T - 1) / CH_T < SF_TPU ? (U.rem + CH_T - 1) / CH_T : SF_TPU;  // the unit's tiles (>= 1)
+    const u32 n_on = (U.rem + SF_T - 1) / SF_T < SF_TPU ? (U.rem + SF_T - 1) / SF_T : SF_TPU;  // the unit's tiles (>= 1)
     const Region R = regions[U.region];
-    bool on[NT], whole = true;
-    u32 tb[NT], rem[NT], rlim[NT];
-    u32 w[NT][8], nw[NT];  // the lane's 32 bytes of each tile and the four bytes behind them
-#pragma unroll
-    for (u32 t = 0; t < NT; t++) {
-        const u32 tu = wv * NT + t;
-        on[t] = tu < n_on;
-        tb[t] = U.tb0 + tu * CH_T;                    // page position of the tile
-        rem[t] = on[t] ? U.rem - tu * CH_T : 0;       // bytes from the tile's start to the end of the page
-        rlim[t] = rem[t] < CH_T ? rem[t] : CH_T;      // bytes of the tile
-        whole = whole && rem[t] >= CH_T + 4;
-    }
+    const bool on = tu < n_on;
+    const u32 tb = U.tb0 + tu * SF_T;                 // page position of the tile
+    const u32 rem = on ? U.rem - tu * SF_T : 0;       // bytes from the tile's start to the end of the page
+    const u32 rlim = rem < SF_T ? rem : SF_T;         // bytes of the tile
+    const u32 sub_lo = lane * SF_SUB;
+    u32* const tl = s_buf[tu];
+    u32 w[NW], nw = 0;  // the lane's bytes of the tile and the four bytes behind them
+    const bool whole = rem >= SF_T + 4;
     if (whole) {
-        // every tile of the wave lies in the page with four bytes behind it: all of the wave's bytes are requested
-        // before the first of them is waited for (tile after tile, each staged before the next is asked for, the
-        // workgroup spent two to four trips to memory here instead of one)
+        // the tile lies in the page with four bytes behind it: all of the lane's bytes are requested before the first of
+        // them is waited for
+        const u8* const p = src_base + U.src_off + (u64)tu * SF_T + sub_lo;
+        u32x4 x[NW / 4];
 #pragma unroll
-        for (u32 t = 0; t < NT; t++) {
-            const u8* const p = src_base + U.src_off + (u64)(wv * NT + t) * CH_T + lane * CH_SUB;
-            const u32x4 a = *(const u32x4_u*)p, b = *(const u32x4_u*)(p + 16);
-            nw[t] = *(const u32_u*)(p + 32);
-            w[t][0] = a.x; w[t][1] = a.y; w[t][2] = a.z; w[t][3] = a.w; w[t][4] = b.x; w[t][5] = b.y; w[t][6] = b.z; w[t][7] = b.w;
-        }
+        for (u32 d = 0; d < NW / 4; d++) x[d] = *(const u32x4_u*)(p + 16 * d);
+        nw = *(const u32_u*)(p + SF_SUB);
 #pragma unroll
-        for (u32 t = 0; t < NT; t++) {
-            u32* const tl = s_buf[wv * NT + t];
-            *(u32x4*)(tl + lane * 8) = u32x4{w[t][0], w[t][1], w[t][2], w[t][3]};
-            *(u32x4*)(tl + lane * 8 + 4) = u32x4{w[t][4], w[t][5], w[t][6], w[t][7]};
-            if (lane == 63) { tl[CH_T / 4] = nw[t]; tl[CH_T / 4 + 1] = 0; }
+        for (u32 d = 0; d < NW / 4; d++) {
+            w[4 * d] = x[d].x; w[4 * d + 1] = x[d].y; w[4 * d + 2] = x[d].z; w[4 * d + 3] = x[d].w;
+            *(u32x4*)(tl + lane * NW + 4 * d) = x[d];
         }
+        if (lane == 63) { tl[SF_T / 4] = nw; tl[SF_T / 4 + 1] = 0; }
+    } else if (on) {
+        sf_stage_tail(src_base + U.src_off + (u64)tu * SF_T, rem, lane, w, tl);
     } else {
 #pragma unroll
-        for (u32 t = 0; t < NT; t++)
-            if (on[t]) str_stage_tile(src_base + U.src_off + (u64)(wv * NT + t) * CH_T, rem[t], 0, lane, w[t], s_buf[wv * NT + t]);
+        for (u32 d = 0; d < NW; d++) w[d] = 0;
     }
-    __builtin_amdgcn_wave_barrier();  // a wave reads only the tile images it wrote itself until the first barrier
+    __builtin_amdgcn_wave_barrier();  // a wave reads only the tile image it wrote itself until the first barrier
     // every load of the wave has arrived (its bytes are in the image).  Said out loud: the compiler does not see it on every
-    // path, and a wait for loads that it puts further down also waits for the stores in flight by then (the status words,
-    // the tile before), a trip to memory each time.
+    // path, and a wait for loads that it puts further down also waits for the stores in flight by then (the status words),
+    // a trip to memory each time.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    if (!whole) {
-#pragma unroll
-        for (u32 t = 0; t < NT; t++) nw[t] = on[t] ? s_buf[wv * NT + t][lane * 8 + 8] : 0;  // the next lane's first word, or the lookahead
-    }
+    if (!whole) nw = on ? tl[lane * NW + NW] : 0;  // the next lane's first word, or the lookahead
     if (stamps && threadIdx.x == 0) { if (s_buf[0][0] == 0x12345678u) stamps[0] = 1; SF_STAMP(1); }  // the read waits for the tile's bytes
 
-    // ---- guess and proof inside each tile (positions relative to the tile)
-    u32 S[NT], cmask[NT], incl[NT];
-    // From a tile's starts S: the lanes' char bytes (every byte of the tile that is no length byte; the bytes in front of
-    // its first start are the tail of the string that enters it) and the running sums of chars (low half) and starts
-    // (high half) over the lanes.  The up to three length bytes that spill in from the tile before are not known yet and
-    // count as chars here.
-    auto prep = [&](u32 t) {
-        const u32 smask = S[t];
-        u32 prev = __shfl_up(smask, 1);
-        if (lane == 0) prev = 0;
-        const u32 lenmask = smask | (smask << 1) | (smask << 2) | (smask << 3) | ((prev >> 29) & 1) | (((prev >> 30) & 1) * 3) |
-                            (((prev >> 31) & 1) * 7);
-        const u32 sub_lo = lane * CH_SUB;
-        const u32 k_hi = rlim[t] >= sub_lo + CH_SUB ? 32 : rlim[t] <= sub_lo ? 0 : rlim[t] - sub_lo;
-        const u32 own = k_hi >= 32 ? 0xFFFFFFFFu : (1u << k_hi) - 1;
-        cmask[t] = own & ~lenmask;
-        incl[t] = sf_wave_scan(__popc(cmask[t]) | (__popc(smask) << 16));
+    // ---- the tile's starts S, the lanes' char bytes (every byte of the tile that is no length byte; the bytes in front of
+    // its first start are the tail of the string that enters it) and the running sums of chars (low half) and starts (high
+    // half) over the lanes.  The up to three length bytes that spill in from the tile before count as chars here.
+    u64 S = 0, cmask = 0;
+    u32 incl = 0;
+    auto prep = [&]() {
+        const u32 prev = sf_lane_below((u32)(S >> 32));  // the last three positions of the lane below hold at most one start
+        const u64 lenmask = S | (S << 1) | (S << 2) | (S << 3) | ((prev >> 29) & 1) | (((prev >> 30) & 1) * 3) | (((prev >> 31) & 1) * 7);
+        u64 own = ~0ull;
+        if (rlim < SF_T) own = rlim >= sub_lo + SF_SUB ? ~0ull : rlim <= sub_lo ? 0ull : (1ull << (rlim - sub_lo)) - 1;
+        cmask = own & ~lenmask;
+        incl = sf_wave_scan((u32)__popcll(cmask) | ((u32)__popcll(S) << 16));
     };
-#pragma unroll
-    for (u32 t = 0; t < NT; t++) {
-        const u32 tu = wv * NT + t;
-        S[t] = 0;
-        if (!on[t]) continue;
-        const u32* const tl = s_buf[tu];
-        const u32 la = (u32)__builtin_amdgcn_readlane((int)nw[t], 63);  // the four bytes behind the tile
-        const u32 W9[9] = {w[t][0], w[t][1], w[t][2], w[t][3], w[t][4], w[t][5], w[t][6], w[t][7], nw[t]};
-        u32 C;
+    // ---- guess and proof inside the tile (positions relative to the tile)
+    if (on) {
+        const u32 la = (u32)__builtin_amdgcn_readlane((int)nw, 63);  // the four bytes behind the tile
+        u64 C;
         static_assert(STR_CAND_MAX == 1u << 20, "sf_small_mask tests for lengths below 2^20");
-        if (rem[t] >= CH_T + 4 + STR_CAND_MAX) {  // every position of the tile has STR_CAND_MAX bytes of page behind it
-            C = sf_small_mask(W9);
+        if (rem >= SF_T + 4 + STR_CAND_MAX) {  // every position of the tile has STR_CAND_MAX bytes of page behind it
+            const u32 W_lo[9] = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]};
+            const u32 W_hi[9] = {w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15], nw};
+            C = sf_small_mask(W_lo) | ((u64)sf_small_mask(W_hi) << 32);
         } else {
-            C = 0;
-            const int room0 = (int)rem[t] - 3 - (int)(lane * CH_SUB);
+            const int room0 = (int)rem - 3 - (int)sub_lo;
+            u32 c2[2] = {0, 0};
 #pragma unroll
-            for (int k = 31; k >= 0; k--) {
-                const u32 x = (k & 3) ? __builtin_amdgcn_alignbit(W9[k / 4 + 1], W9[k / 4], (k & 3) * 8) : W9[k / 4];
-                C = (C << 1) | (u32)(x < str_cand_room(room0 - k));
+            for (int k = 63; k >= 0; k--) {
+                const u32 hi_w = k / 4 + 1 < (int)NW ? w[(k / 4 + 1) & 15] : nw;
+                const u32 x = (k & 3) ? __builtin_amdgcn_alignbit(hi_w, w[k / 4], (k & 3) * 8) : w[k / 4];
+                c2[k >> 5] = (c2[k >> 5] << 1) | (u32)(x < str_cand_room(room0 - k));
             }
+            C = c2[0] | ((u64)c2[1] << 32);
         }
-        u32 c_next = __shfl_down(C, 1) & 1;
-        if (lane == 63) c_next = la < str_cand_room((int)rem[t] - 3 - (int)CH_T);
-        const u32 Sm = C & ~((C >> 1) | (c_next << 31));
+        u32 c_next = sf_lane_above((u32)C) & 1;
+        if (lane == 63) c_next = la < str_cand_room((int)rem - 3 - (int)SF_T);
+        const u64 Sm = C & ~((C >> 1) | ((u64)c_next << 63));
         // the first guessed start in the lanes above mine (nf), and of the tile (ent): the lanes that hold a start, as a
         // mask, say which lane to ask
         const u64 has = __ballot(Sm != 0);
-        const u32 first = lane * CH_SUB + (u32)__ffs(Sm) - 1;
+        const u32 first = sub_lo + (u32)__ffsll((unsigned long long)Sm) - 1;
         const u64 above = (has >> 1) >> lane;
         const u32 nfl = __shfl(first, above ? (int)lane + (int)__ffsll((unsigned long long)above) : 0);
-        const u32 nf = above ? nfl : 0xFFFFu;
-        const u32 ent = has ? (u32)__builtin_amdgcn_readlane((int)first, __ffsll((unsigned long long)has) - 1) : 0xFFFFu;
+        const u32 nf = above ? nfl : NONE;
+        const u32 ent = has ? (u32)__builtin_amdgcn_readlane((int)first, __ffsll((unsigned long long)has) - 1) : NONE;
         // the proof inside the tile.  A start with another start behind it in the same lane: its end is that one (lanes
         // with several starts go round together); the lane's last start: its end is the first start of the lanes above,
         // or, for the tile's last start, lies at or beyond the tile's end (the tile's exit)
-        const u32 sub_lo = lane * CH_SUB;
-        u32 bad = 0, mi = Sm;
+        bool bad = false;
+        u64 mi = Sm;
         while (true) {
-            const u32 m2 = mi & (mi - 1);
+            const u64 m2 = mi & (mi - 1);
             if (!__any(m2 != 0)) break;
-            const u32 k = ((u32)__ffs(mi) - 1) & 31, k2 = (u32)__ffs(m2) - 1;
+            const u32 k = ((u32)__ffsll((unsigned long long)mi) - 1) & 63, k2 = (u32)__ffsll((unsigned long long)m2) - 1;
             const u32 len = str_len_at(tl, sub_lo + k);
-            bad |= (u32)(m2 != 0) & (u32)(k + 4 + len != k2);
+            bad = bad | ((m2 != 0) & (k + 4 + len != k2));
             mi = m2 ? m2 : mi;
         }
-        const u32 pl = sub_lo + ((31 - (u32)__clz((int)Sm)) & 31);  // the lane's last start (anything in a lane without one)
-        const u32 nxl = pl + 4 + str_len_at(tl, pl);               // a candidate's length fits in the page
-        bad |= (u32)(Sm != 0) & (u32)(above ? nxl != nf : nxl < rlim[t]);
-        const bool ok = !__any(bad != 0);
-        S[t] = Sm;
-        prep(t);
-        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)incl[t], 63) >> 16;
+        const u32 pl = sub_lo + ((63 - (u32)__clzll((long long)Sm)) & 63);  // the lane's last start (anything in a lane without one)
+        const u32 nxl = pl + 4 + str_len_at(tl, pl);                       // a candidate's length fits in the page
+        bad = bad | ((Sm != 0) & (above ? nxl != nf : nxl < rlim));
+        const bool ok = !__any(bad);
+        S = Sm;
+        prep();
+        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)incl, 63) >> 16;
         u32 ext = SF_PASS, spill = 0;
         if (has) {
             const int l = 63 - (int)__clzll((unsigned long long)has);  // the lane of the tile's last start
-            ext = tb[t] + (u32)__builtin_amdgcn_readlane((int)nxl, l);
+            ext = tb + (u32)__builtin_amdgcn_readlane((int)nxl, l);
             const u32 lq = (u32)__builtin_amdgcn_readlane((int)pl, l);
-            spill = lq + 4 > rlim[t] ? lq + 4 - rlim[t] : 0;
+            spill = lq + 4 > rlim ? lq + 4 - rlim : 0;
         }
         if (lane == 0) {
             s_cnt[tu] = ok ? cnt : BAD;
-            s_ent[tu] = tb[t] + ent;
+            s_ent[tu] = tb + ent;
             s_ext[tu] = ext;
             s_spill[tu] = spill;
             s_slot[tu] = BAD;
@@ -1386,53 +1401,58 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
     SF_STAMP(3);
     const bool all_ok = !__ballot(lane < n_on && s_cnt[lane < n_on ? lane : 0] == BAD);  // the same in every wave
 
-    // ---- offsets and chars of a tile, in two steps.  Every byte of a tile that is no length byte is a char (the bytes in
-    // front of its first start are the tail of the string that enters it), so a tile moves exactly its own bytes.
-    // Step 1 needs the tile's starts and nothing from other tiles: the chars are compacted into the tile's LDS image (the
-    // up to three length bytes that spill in from the tile before still count as chars and lead them).  Step 2 needs the
-    // spill and the rank of the tile's first string: string number g at stream position q has its chars at q - 4 g, so
-    // the tile's chars go to (stream position of the tile) + spill - 4 (strings before it).
-    u32 n_all[NT], a3[NT], ps[NT];
-    auto compact = [&](u32 t) {
-        const u32 tu = wv * NT + t;
-        const u32 charmask = cmask[t];
-        const u32 excl = incl[t] - (__popc(cmask[t]) | (__popc(S[t]) << 16));
-        n_all[t] = (u32)__builtin_amdgcn_readlane((int)incl[t], 63) & 0xFFFF;
-        const u32 pc = excl & 0xFFFF;
-        ps[t] = excl >> 16;
+    // ---- offsets and chars of the tile, in two steps.  Every byte of a tile that is no length byte is a char, so a tile
+    // moves exactly its own bytes.  Step 1 needs the tile's starts and nothing from other tiles: the chars are compacted
+    // into the tile's LDS image (the up to three length bytes that spill in from the tile before still count as chars and
+    // lead them), the offsets, less what the rank adds, go behind them.  Step 2 needs the spill and the rank of the tile's
+    // first string: string number g at stream position q has its chars at q - 4 g, so the tile's chars go to (stream
+    // position of the tile) + spill - 4 (strings before it).
+    u32 n_all = 0, a3 = 0;
+    auto compact = [&]() {
+        const u32 excl = incl - ((u32)__popcll(cmask) | ((u32)__popcll(S) << 16));
+        n_all = (u32)__builtin_amdgcn_readlane((int)incl, 63) & 0xFFFF;
+        const u32 pc = excl & 0xFFFF, ps = excl >> 16;
         // the chars keep their place within a 4-byte word of the destination whatever the rank turns out to be (it moves
         // them by a multiple of 4): byte i of the tile that is no length byte goes to byte a3 + i of the image
-        a3[t] = (u32)((uintptr_t)R.out2 + R.run_base + tb[t]) & 3;
-        u8* const stage = (u8*)s_buf[tu];  // every read of the tile image is over
+        a3 = (u32)((uintptr_t)R.out2 + R.run_base + tb) & 3;
         // from the lane's last byte down: shifting the mask out at the top gives the byte's bit as a carry, which both
-        // moves the address down by one and decides the store (two instructions a byte)
-        u32 mk = charmask;
-        u8* ap = stage + (a3[t] + pc + __popc(charmask));
+        // moves the address down by one and decides the store (two instructions a byte); every read of the image is over
+        u8* ap = (u8*)tl + (a3 + pc + (u32)__popcll(cmask));
 #pragma unroll
-        for (int k = (int)CH_SUB - 1; k >= 0; k--) {
-            const bool c = __builtin_add_overflow(mk, mk, &mk);
-            ap -= c;
-            const u32 x = (k & 1) ? w[t][k >> 2] >> 8 : w[t][k >> 2];  // bytes 1 and 3 of a word share one shift
-            if (c && !(SF_EXP & 4)) *ap = (u8)((k & 2) ? x >> 16 : x);
+        for (int h = 1; h >= 0; h--) {
+            u32 mk = (u32)(cmask >> (32 * h));
+#pragma unroll
+            for (int k = 31; k >= 0; k--) {
+                const bool c = __builtin_add_overflow(mk, mk, &mk);
+                ap -= c;
+                const u32 wd = w[8 * h + (k >> 2)];
+                const u32 x = (k & 1) ? wd >> 8 : wd;  // bytes 1 and 3 of a word share one shift
+                if (c && !(SF_EXP & 4)) *ap = (u8)((k & 2) ? x >> 16 : x);
+            }
         }
-        // The tile's offsets, less what the rank adds, go into the words of the image behind the chars: every start took
-        // four length bytes out of the chars, so there is room for exactly its offset (at most a3 + spill + alignment =
-        // 9 bytes more than the tile, and the image has 16).  From there they are stored in rank order, lane by lane.
-        u32* const ow = s_buf[tu] + ((a3[t] + n_all[t] + 3) >> 2) + ps[t];
-        u32 m = S[t], v = lane * CH_SUB - 4 * ps[t], j = 0;
-        while (m) {
-            ow[j++] = v + (u32)__ffs(m) - 1;
-            m &= m - 1;
-            v -= 4;
+        // Every start took four length bytes out of the chars, so behind them there is room for exactly its offset (at
+        // most a3 + spill + alignment = 9 bytes more than the tile, and the image has 16).  From there the offsets are
+        // stored in rank order, lane by lane.
+        u32* ow = tl + ((a3 + n_all + 3) >> 2) + ps;
+        u32 v = sub_lo - 4 * ps;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            u32 m = (u32)(S >> (32 * h));
+            while (m) {
+                *ow++ = v + (u32)__ffs(m) - 1;
+                m &= m - 1;
+                v -= 4;
+            }
+            v += 32;
         }
     };
 
     // ---- the unit: ranks, the proof between tiles, repairs (wave 0), while the other waves compact their chars
-    if (wv == 0) {
+    if (tu == 0) {
         const bool mine = lane < n_on;
         u32 c = mine ? s_cnt[lane] : 0, e = mine ? s_ext[lane] : SF_PASS;
         const u32 en = mine ? s_ent[lane] : 0;
-        const u32 t_lim = U.tb0 + ((lane + 1) * CH_T < U.rem ? (lane + 1) * CH_T : U.rem);
+        const u32 t_lim = U.tb0 + ((lane + 1) * SF_T < U.rem ? (lane + 1) * SF_T : U.rem);
         const u32 cf = R.lv_base, rf = R.count_level;
         u32* const cfail = chunk_failed + R.otile_base;
         const u64 m_ex = __ballot(mine && e != SF_PASS);  // tiles with an exit of their own
@@ -1442,10 +1462,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
             tot = sf_wave_sum(c);
             if (m_ex) uexit = __shfl(e, 63 - (int)__clzll((unsigned long long)m_ex));
             if (lane == 0) sf_store(ustat + ui, sf_pack(SF_AGG, uspill0, tot, uexit));
-            // its own tiles before it looks back: the units in front need the time anyway
-#pragma unroll
-            for (u32 t = 0; t < NT; t++)
-                if (on[t]) compact(t);
+            compact();  // its own tile before it looks back: the units in front need the time anyway
         }
         u32 uexcl = 0, pexit = 0, pspill = 0;
         SF_STAMP(4);
@@ -1457,15 +1474,15 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
             const u64 below = m_ex & ((1ull << lane) - 1);
             const u32 e_below = __shfl(e, below ? 63 - (int)__clzll((unsigned long long)below) : 0);  // every lane takes part: a lane outside a shuffle is read as 0
             const u32 pe = below ? e_below : pexit;
-            const bool bad = mine && (c ? en != pe : pe < t_lim);
-            if (__ballot(bad)) alive = false;
+            const bool wrong = mine && (c ? en != pe : pe < t_lim);
+            if (__ballot(wrong)) alive = false;
             if (uexit == SF_PASS) uexit = pexit;
         } else if (alive) {
             // some guess failed: one lane goes through the tiles in order and walks the failed ones string by string
             if (lane == 0) {
                 u32 pe = pexit, nrep = 0;
                 for (u32 t = 0; t < n_on && alive; t++) {
-                    const u32 tbt = U.tb0 + t * CH_T, remt = U.rem - t * CH_T, rend = remt < CH_T ? remt : CH_T, limt = tbt + rend;
+                    const u32 tbt = U.tb0 + t * SF_T, remt = U.rem - t * SF_T, rend = remt < SF_T ? remt : SF_T, limt = tbt + rend;
                     const u32 ct = s_cnt[t];
                     if (ct != BAD) {
                         if (ct ? s_ent[t] != pe : pe < limt) { alive = false; break; }
@@ -1475,14 +1492,14 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
                     if (nrep == SF_REP_MAX) { alive = false; break; }
                     u32 n = 0, spill = 0;
                     u32* const bits = s_bits[nrep];
-                    for (u32 i = 0; i < 64; i++) bits[i] = 0;
+                    for (u32 i = 0; i < SF_T / 32; i++) bits[i] = 0;
                     if (pe < limt) {
-                        const u32* const tl = s_buf[t];
+                        const u32* const tlt = s_buf[t];
                         const u32 room0 = remt - 3, rend4 = remt < 4 ? 0 : rend < room0 ? rend : room0;
                         u32 rel = pe - tbt, last_rel = rel;
                         while (rel < rend4) {
                             bits[rel >> 5] |= 1u << (rel & 31);
-                            const u32 len = str_len_at(tl, rel);
+                            const u32 len = str_len_at(tlt, rel);
                             last_rel = rel;
                             rel = len < room0 - rel ? rel + 4 + len : ERR_POS;
                             n++;
@@ -1509,8 +1526,8 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
         }
         if (alive && (u64)uexcl + tot > SF_CNT_MAX) alive = false;
         if (alive) {
-            const u32 incl = sf_wave_scan(c);
-            if (mine) s_excl[lane] = uexcl + incl - c;
+            const u32 ci = sf_wave_scan(c);
+            if (mine) s_excl[lane] = uexcl + ci - c;
             if (lane == 0) { sf_store(ustat + ui, sf_pack(SF_INCL, uspill, uexcl + tot, uexit)); s_spin0 = pspill; }
         } else if (lane == 0) {
             __hip_atomic_store(cfail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1519,68 +1536,59 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
         }
         if (lane == 0) s_alive = alive;
         SF_STAMP(6);
-    } else if (all_ok) {
-#pragma unroll
-        for (u32 t = 0; t < NT; t++)
-            if (on[t]) compact(t);
+    } else if (all_ok && on) {
+        compact();
     }
     __syncthreads();
-    if (!s_alive) return;
+    if (!s_alive || !on) return;
     SF_STAMP(7);
     if (!all_ok) {  // after a repair: the starts of a walked tile come from the walk
-#pragma unroll
-        for (u32 t = 0; t < NT; t++) {
-            const u32 tu = wv * NT + t;
-            if (!on[t]) continue;
-            if (s_slot[tu] != BAD) { S[t] = s_bits[s_slot[tu]][lane]; prep(t); }
-            compact(t);
+        if (s_slot[tu] != BAD) {
+            const u32* const bits = s_bits[s_slot[tu]];
+            S = bits[2 * lane] | ((u64)bits[2 * lane + 1] << 32);
+            prep();
         }
+        compact();
     }
     __builtin_amdgcn_wave_barrier();
     SF_STAMP(8);
-#pragma unroll
-    for (u32 t = 0; t < NT; t++) {
-        if (!on[t]) continue;
-        const u32 tu = wv * NT + t;
-        const u32 excl = s_excl[tu];
-        const u32 spin = tu == 0 ? s_spin0 : s_spill[tu - 1];
-        const u64 q0 = R.run_base + tb[t] + spin;  // stream position of the tile's first byte that is no spilled length byte
-        if (q0 < 4ull * excl) {  // only a rank from a wrong guess elsewhere can do this: the chunk is being given up
-            if (lane == 0) {
-                __hip_atomic_store(chunk_failed + R.otile_base, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(any_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            continue;
+    const u32 excl = s_excl[tu];
+    const u32 spin = tu == 0 ? s_spin0 : s_spill[tu - 1];
+    const u64 q0 = R.run_base + tb + spin;  // stream position of the tile's first byte that is no spilled length byte
+    if (q0 < 4ull * excl) {  // only a rank from a wrong guess elsewhere can do this: the chunk is being given up
+        if (lane == 0) {
+            __hip_atomic_store(chunk_failed + R.otile_base, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(any_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        {
-            int32_t* const offs = (int32_t*)R.out + excl;
-            const u32 cap = R.width > excl ? R.width - excl : 0;  // entries of the chunk's offsets array in front of the closing one
-            const u32 cnt = (u32)__builtin_amdgcn_readlane((int)incl[t], 63) >> 16;
-            const u32 n = cnt < cap ? cnt : cap;
-            const u32* const ow = s_buf[tu] + ((a3[t] + n_all[t] + 3) >> 2);
-            const u32 add = (u32)R.run_base + tb[t] - 4u * excl;
-#pragma unroll 1
-            for (u32 i = lane; i < n; i += 64)
-                if (!(SF_EXP & 1)) *as_global(offs + i) = (int32_t)(ow[i] + add);
-        }
-        SF_STAMP(11 + 2 * t);
-        u8* const cd = R.out2 + (q0 - 4ull * excl);
-        // byte i of the tile's chars is byte a3 + spin + i of the image and goes to cd + i; pd0 % 4 == (a3 + spin) % 4
-        const u32 pd0 = (u32)((uintptr_t)cd & 15);
-        const int shift = (int)pd0 - (int)(a3[t] + spin);              // a multiple of 4 between -4 and 12
-        const u8* const stage = (const u8*)s_buf[tu] - shift;          // stage[pd0 + i] = byte i of the tile's chars
-        const u32 n_stg = pd0 + n_all[t] - spin;
-        // aligned 16-byte stores between the first and the last 16-byte boundary; the up to 15 bytes on either side go one per lane
-        const u32 head_end = ((pd0 + 15) & ~15u) < n_stg ? ((pd0 + 15) & ~15u) : n_stg;
-        const u32 tail_lo = (n_stg & ~15u) > head_end ? (n_stg & ~15u) : head_end;
-        for (u32 c0 = head_end + lane * 16; c0 < tail_lo; c0 += 64 * 16) {
-            const u32* const sp = (const u32*)(stage + c0);  // 4-byte aligned
-            if (!(SF_EXP & 2)) *as_global((u32x4*)(cd - pd0 + c0)) = u32x4{sp[0], sp[1], sp[2], sp[3]};
-        }
-        if (lane < 16) { if (pd0 + lane < head_end) *as_global(cd + lane) = stage[pd0 + lane]; }
-        else if (lane < 32) { const u32 b = tail_lo + lane - 16; if (b < n_stg) *as_global(cd + (b - pd0)) = stage[b]; }
-        SF_STAMP(12 + 2 * t);
+        return;
     }
+    {
+        int32_t* const offs = (int32_t*)R.out + excl;
+        const u32 cap = R.width > excl ? R.width - excl : 0;  // entries of the chunk's offsets array in front of the closing one
+        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)incl, 63) >> 16;
+        const u32 n = cnt < cap ? cnt : cap;
+        const u32* const ow = tl + ((a3 + n_all + 3) >> 2);
+        const u32 add = (u32)R.run_base + tb - 4u * excl;
+#pragma unroll 1
+        for (u32 i = lane; i < n; i += 64)
+            if (!(SF_EXP & 1)) *as_global(offs + i) = (int32_t)(ow[i] + add);
+    }
+    u8* const cd = R.out2 + (q0 - 4ull * excl);
+    // byte i of the tile's chars is byte a3 + spin + i of the image and goes to cd + i; pd0 % 4 == (a3 + spin) % 4
+    const u32 pd0 = (u32)((uintptr_t)cd & 15);
+    const int shift = (int)pd0 - (int)(a3 + spin);                 // a multiple of 4 between -4 and 12
+    const u8* const stage = (const u8*)tl - shift;                 // stage[pd0 + i] = byte i of the tile's chars
+    const u32 n_stg = pd0 + n_all - spin;
+    // aligned 16-byte stores between the first and the last 16-byte boundary; the up to 15 bytes on either side go one per lane
+    const u32 head_end = ((pd0 + 15) & ~15u) < n_stg ? ((pd0 + 15) & ~15u) : n_stg;
+    const u32 tail_lo = (n_stg & ~15u) > head_end ? (n_stg & ~15u) : head_end;
+#pragma unroll 1
+    for (u32 c0 = head_end + lane * 16; c0 < tail_lo; c0 += 64 * 16) {
+        const u32* const sp = (const u32*)(stage + c0);  // 4-byte aligned
+        if (!(SF_EXP & 2)) *as_global((u32x4*)(cd - pd0 + c0)) = u32x4{sp[0], sp[1], sp[2], sp[3]};
+    }
+    if (lane < 16) { if (pd0 + lane < head_end) *as_global(cd + lane) = stage[pd0 + lane]; }
+    else if (lane < 32) { const u32 b = tail_lo + lane - 16; if (b < n_stg) *as_global(cd + (b - pd0)) = stage[b]; }
     SF_STAMP(9);
     if (stamps && threadIdx.x == 0) stamps[(u64)blockIdx.x * SF_STAMPS + 15] = (u64)clock64() - cyc0;
 #undef SF_STAMP
@@ -1605,7 +1613,7 @@ __global__ void k_str_totals(const Region* __restrict__ regions, u32 n_regions,
     const Region R = regions[r];
     if (chunk_failed[R.otile_base]) return;
     // units of the page: [lo, hi); units of one chunk are numbered in page order from cf
-    const u32 lo = R.count_level, hi = lo + (R.len + SF_TPU * CH_T - 1) / (SF_TPU * CH_T), cf = R.lv_base;
+    const u32 lo = R.count_level, hi = lo + (R.len + SF_UNIT - 1) / SF_UNIT, cf = R.lv_base;
     const u32 before = lo > cf ? (u32)(ustat[lo - 1] >> 32) & SF_CNT_MAX : 0;
     const u32 upto = hi > cf ? (u32)(ustat[hi - 1] >> 32) & SF_CNT_MAX : 0;
     RegionTotal T;
@@ -2221,10 +2229,12 @@ __global__ __launch_bounds__(64) void k_page_scan(const ChunkRec* __restrict__ c
 // One workgroup per page: it owns the 64-level words that START inside the page; the page's first value index
 // comes from k_page_scan.  Entry ceil(n_levels / 64) (the total) is written by k_page_scan.
 // =====================================================================================
-__global__ __launch_bounds__(1024) void k_value_index(const ChunkRec* __restrict__ chunks, const PageRec* __restrict__ pages,
-                                                      const PageDyn* __restrict__ page_dyn, const u32* __restrict__ page_ids,
-                                                      const u64* __restrict__ page_lvl_off) {
-    __shared__ u32 s_w[16], s_carry;
+// Workgroups of four waves, like those of the long kernels that run beside this one: a workgroup of sixteen waves needs
+// sixteen free wave slots on one CU at once and waited a millisecond for them behind the string pass and the gather.
+__global__ __launch_bounds__(256) void k_value_index(const ChunkRec* __restrict__ chunks, const PageRec* __restrict__ pages,
+                                                     const PageDyn* __restrict__ page_dyn, const u32* __restrict__ page_ids,
+                                                     const u64* __restrict__ page_lvl_off) {
+    __shared__ u32 s_w[4], s_carry;
     const u32 pg = page_ids[blockIdx.x];
     const PageRec P = pages[pg];
     const ChunkRec C = chunks[P.chunk];
@@ -2241,23 +2251,27 @@ __global__ __launch_bounds__(1024) void k_value_index(const ChunkRec* __restrict
         s_carry = (u32)page_dyn[pg].val_off + head;
     }
     __syncthreads();
-    for (u64 base = w0; base < w1; base += 1024) {
-        const u64 w = base + tid;
-        const u32 c = w < w1 ? (u32)__popcll(vb[w]) : 0;
-        u32 incl = c;
-        for (int d = 1; d < 64; d <<= 1) {
-            const u32 t = __shfl_up(incl, d);
-            if (lane >= (u32)d) incl += t;
-        }
+    for (u64 base = w0; base < w1; base += 1024) {  // four consecutive words per thread
+        const u64 w = base + tid * 4;
+        u32 c[4];
+#pragma unroll
+        for (u32 i = 0; i < 4; i++) c[i] = w + i < w1 ? (u32)__popcll(as_global(vb)[w + i]) : 0;
+        const u32 mine = c[0] + c[1] + c[2] + c[3];
+        const u32 incl = sf_wave_scan(mine);
         if (lane == 63) s_w[wv] = incl;
         __syncthreads();
         u32 before = s_carry, total = 0;
 #pragma unroll
-        for (u32 q = 0; q < 16; q++) {
+        for (u32 q = 0; q < 4; q++) {
             if (q < wv) before += s_w[q];
             total += s_w[q];
         }
-        if (w < w1) out[w] = before + incl - c;
+        u32 run = before + incl - mine;
+#pragma unroll
+        for (u32 i = 0; i < 4; i++) {
+            if (w + i < w1) *as_global(out + w + i) = run;
+            run += c[i];
+        }
         __syncthreads();
         if (tid == 0) s_carry += total;
     }
@@ -2784,18 +2798,19 @@ __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunk
     }
 }
 
-__global__ __launch_bounds__(1024) void k_rows_scan(const ChunkRec* __restrict__ chunks, const u32* __restrict__ rtile_prefix,
-                                                    const u32* __restrict__ chunk_ids, u32 n_rchunks,
-                                                    RowTile* __restrict__ tiles, ChunkDyn* __restrict__ chunk_dyn) {
-    __shared__ u64 s_r[16], s_v[16];
+__global__ __launch_bounds__(256) void k_rows_scan(const ChunkRec* __restrict__ chunks, const u32* __restrict__ rtile_prefix,
+                                                   const u32* __restrict__ chunk_ids, u32 n_rchunks,
+                                                   RowTile* __restrict__ tiles, ChunkDyn* __restrict__ chunk_dyn) {
+    __shared__ u64 s_r[4], s_v[4];
     const u32 k = blockIdx.x;
     if (k >= n_rchunks) return;
     const u32 c = chunk_ids[k];
     const ChunkRec C = chunks[c];
-    // every thread owns a contiguous slice of the chunk's tiles: slice sums, block scan, slice bases
+    // every thread owns a contiguous slice of the chunk's tiles: slice sums, block scan, slice bases (four waves: a
+    // larger workgroup waits long for room on one CU while the long kernels of the other streams run)
     const u32 t0 = rtile_prefix[k], t1 = rtile_prefix[k + 1];
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 per = (t1 - t0 + 1023) / 1024;
+    const u32 per = (t1 - t0 + 255) / 256;
     const u32 a = t0 + tid * per < t1 ? t0 + tid * per : t1, b = a + per < t1 ? a + per : t1;
     u64 r = 0, v = 0;
     for (u32 t = a; t < b; t++) { r += tiles[t].rows; v += tiles[t].vals; }
@@ -2807,7 +2822,7 @@ __global__ __launch_bounds__(1024) void k_rows_scan(const ChunkRec* __restrict__
     if (lane == 63) { s_r[wv] = sr; s_v[wv] = sv; }
     __syncthreads();
     u64 base_r = 0, base_v = 0, tot_r = 0, tot_v = 0;
-    for (u32 q = 0; q < 16; q++) {
+    for (u32 q = 0; q < 4; q++) {
         if (q < wv) { base_r += s_r[q]; base_v += s_v[q]; }
         tot_r += s_r[q]; tot_v += s_v[q];
     }
@@ -2952,7 +2967,7 @@ hipError_t launch_page_scan(hipStream_t st, const ChunkRec* chunks, u32 n_chunks
 hipError_t launch_value_index(hipStream_t st, const ChunkRec* chunks, const PageRec* pages, const PageDyn* page_dyn,
                               const u32* page_ids, u32 n_pages, const u64* page_lvl_off) {
     if (n_pages == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_value_index, dim3(n_pages), dim3(1024), 0, st, chunks, pages, page_dyn, page_ids, page_lvl_off);
+    hipLaunchKernelGGL(k_value_index, dim3(n_pages), dim3(256), 0, st, chunks, pages, page_dyn, page_ids, page_lvl_off);
     LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -3009,7 +3024,7 @@ hipError_t launch_rows(hipStream_t st, const ChunkRec* chunks, const u32* rtile_
                            n_rtiles, tiles);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_rows_scan, dim3(n_rchunks), dim3(1024), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles, chunk_dyn);
+    hipLaunchKernelGGL(k_rows_scan, dim3(n_rchunks), dim3(256), 0, st, chunks, rtile_prefix, chunk_ids, n_rchunks, tiles, chunk_dyn);
     LAUNCH_CHECK();
     if (n_rtiles) {
         hipLaunchKernelGGL((k_rows<true>), dim3(n_rtiles), dim3(256), 0, st, chunks, rtile_prefix, rtile_owner, chunk_ids, n_rchunks, tiles);

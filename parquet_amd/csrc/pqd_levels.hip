@@ -104,6 +104,22 @@ static __device__ __forceinline__ void lv_header4(u32 lo, u32 p, u32 L, u32 w, u
     vals = bad ? 0 : bp ? cnt * 8 : cnt;
 }
 
+// The sweep's header parse: a header of one or two bytes (fewer than 2^13 values or groups: every bit-packed run of
+// the reference writer, rle.go:69-71, and RLE runs of up to 8191 values) at position p that lies at least 8 bytes in
+// front of the block end, from the 2 bytes at p.  n = header bytes, 0 for a longer header (nothing else is valid then: the
+// sweep marks the start FAR, and the true chain, should it come here, parses it with full arithmetic).  Half the
+// instructions of lv_header4, and the sweep runs it on every byte.
+static __device__ __forceinline__ void lv_header2(u32 lo, u32 p, u32 L, u32 w, u32 bw, u32& n, u32& nxt, u32& vals) {
+    const bool one = !(lo & 0x80), two = !(lo & 0x8000);
+    const u32 h = one ? lo & 0x7F : (lo & 0x7F) | ((lo >> 1) & 0x3F80);
+    n = one ? 1 : two ? 2 : 0;
+    const u32 q = p + n, cnt = h >> 1;
+    const bool bp = (h & 1) != 0;
+    const u32 bp_nxt = q + __umul24(w, cnt);  // < 2^16 bytes on
+    nxt = bp ? (bp_nxt < L ? bp_nxt : L) : q + bw;
+    vals = bp ? cnt * 8 : cnt;  // < 2^16
+}
+
 // One run of the true chain at position q, parsed from the image (r = q - start of the super-tile): next header, values,
 // and how to produce them: info = value << 1 for an RLE run (width <= 8), position of the packed bytes << 1 | 1
 // for a bit-packed run, whose first 32 packed bits are pay32 when pay_ok.
@@ -273,6 +289,25 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     // ---- 1. sweep: where the chain of every start leaves my 16 bytes, and the values it passes on the way
     auto sweep = [&](auto tail_c) {
         constexpr bool TAIL = decltype(tail_c)::value;  // false: my 16 bytes and 8 more lie inside the block
+        if constexpr (!TAIL) {
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            const u32 bw = (width + 7) >> 3;
+#pragma unroll
+            for (int k = (int)LV_SUB - 1; k >= 0; k--) {
+                u32 n, nxt, vals;
+                lv_header2(lv_win32(w, k), sub_lo + k, L, width, bw, n, nxt, vals);
+                const bool in = (n != 0) & (nxt < sub_hi);  // lands on a later start of mine: its answer is final
+                const u32 mi = (u32)k * LV_PITCH + tid;
+                const u32 t2 = *(const u32*)((const u8*)memo0 + (in ? __umul24(nxt - sub_lo, LV_PITCH * 4) + tid * 4 : mi * 4));
+                const u32 d = nxt - sb;
+                const u32 enc = n == 0 ? LV_FAR : d < LV_FAR ? d : LV_FAR;  // a longer header: parsed with full arithmetic if the true chain comes here
+                // exit in the low half, values in the high half, added with saturation (LV_VSAT: that many or more, or unknown)
+                const u32 base = in ? t2 : enc, add = (in | (enc < LV_FAR)) ? vals << 16 : LV_VSAT << 16;
+                const u16x2 sum = __builtin_elementwise_add_sat(__builtin_bit_cast(u16x2, base), __builtin_bit_cast(u16x2, add));
+                memo0[mi] = __builtin_bit_cast(u32, sum);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = (int)LV_SUB - 1; k >= 0; k--) {
             const u32 p = sub_lo + k;

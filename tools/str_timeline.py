@@ -47,9 +47,6 @@ def main():
         d = us[:, i] - us[:, i - 1]
         print("%-28s %9.2f %9.2f %9.2f | %9.1f %9.1f" % (NAMES[i], np.median(d), np.percentile(d, 90), d.max(), us[:, i].min(), us[:, i].max()))
     print("unit record arrived: median %.2f p90 %.2f" % (np.median(us[:, 10] - us[:, 0]), np.percentile(us[:, 10] - us[:, 0], 90)))
-    for a, b, nm in ((8, 11, "offsets tile 0"), (11, 12, "chars tile 0"), (12, 13, "offsets tile 1"), (13, 14, "chars tile 1")):
-        d = us[:, b] - us[:, a]
-        print("  %-20s median %.2f p90 %.2f" % (nm, np.median(d), np.percentile(d, 90)))
     mhz = st[:, 15] / np.maximum(us[:, 9] - us[:, 0], 0.01)
     print("shader clock over the workgroups' lives: median %.0f MHz (p10 %.0f, p90 %.0f)" % (np.median(mhz), np.percentile(mhz, 10), np.percentile(mhz, 90)))
     print("start times: median %.1f p90 %.1f max %.1f" % (np.median(us[:, 0]), np.percentile(us[:, 0], 90), us[:, 0].max()))
