@@ -21,9 +21,19 @@ constexpr int ST_CORRUPT = 1, ST_NONCANONICAL = 2, ST_UNSUPPORTED = 3, ST_INTERN
 constexpr int PT_BOOLEAN = 0, PT_BYTE_ARRAY = 6;
 
 // ---- PLAIN value gather -------------------------------------------------------------------
-constexpr int CP_THREADS = 256;
-constexpr int CP_UNROLL = 1;
-constexpr u32 CP_BLK = CP_THREADS * 16 * CP_UNROLL;  // bytes per block (4 KiB): many small blocks beat a grid-stride loop here
+// One wave per workgroup, 16 bytes per lane.  Measured on the batch of all column kinds (the gather beside the level and
+// string kernels) and on the gather alone: 64 x 1: 3.48 ms / 6.00 TB/s; 256 x 1: 3.60 / 6.03; 128 x 2: 3.62 / 5.95;
+// 256 x 2: 3.54 / 5.86; 64 x 4: 3.84 / 5.45.  Workgroups of one wave fill single wave slots as the four-wave workgroups
+// of the other kernels leave them.
+#ifndef CP_THREADS_N
+#define CP_THREADS_N 64
+#endif
+#ifndef CP_UNROLL_N
+#define CP_UNROLL_N 1
+#endif
+constexpr int CP_THREADS = CP_THREADS_N;
+constexpr int CP_UNROLL = CP_UNROLL_N;
+constexpr u32 CP_BLK = CP_THREADS * 16 * CP_UNROLL;  // bytes per block (1 KiB): many small blocks beat a grid-stride loop here
 constexpr u32 CP_GRP = 256;  // the planner tabulates the segment of every CP_GRP-th block: a block finds its own from there in a step or two
 
 struct Seg {
@@ -159,7 +169,10 @@ hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs
 // Region fields on this path: count_level = first unit of the region, lv_base = first unit of the region's chunk,
 // run_base = bytes of the chunk's earlier pages (values regions), width = entries of the chunk's offsets array,
 // otile_base = index of the chunk among the BYTE_ARRAY chunks.
-constexpr u32 SF_WAVES = 4;                    // waves per workgroup (unit)
+#ifndef SF_WAVES_N
+#define SF_WAVES_N 4
+#endif
+constexpr u32 SF_WAVES = SF_WAVES_N;           // waves per workgroup (unit)
 constexpr u32 SF_SUB = 64, SF_T = 64 * SF_SUB; // bytes per lane and per tile of this kernel (a tile is one wave's)
 constexpr u32 SF_TPU = SF_WAVES;               // tiles per unit
 constexpr u32 SF_UNIT = SF_TPU * SF_T;         // bytes per unit

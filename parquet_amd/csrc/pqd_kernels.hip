@@ -1175,9 +1175,14 @@ static __device__ __forceinline__ bool sf_lookback(const u64* __restrict__ ustat
                                                    u32 lane, u32& excl, u32& pexit, u32& pspill) {
     // SF_LB blocks of 64 words are asked for per trip and gone through nearest first.  One block: with four, a batch of
     // two chunks (a thousand units of each in flight, the nearest inclusive prefix 100-200 units back) was slower, not
-    // faster (0.76 against 0.64 ms): what a unit waits for there is the slowest of the units in front of it to publish
-    // at all, and four times the polling traffic on the same words made every trip longer.
-    constexpr int SF_LB = 1;
+    // faster (0.67 against 0.59 ms; two blocks: 0.63): what a unit waits for there is the slowest of the units in front
+    // of it to publish at all, and the more words it looks at, the more often one of them is late.  Asking for the
+    // first block before the wave compacts its own tile, to look at it afterwards, gained nothing either: the units
+    // right in front publish about when this one does, so the words have to be asked for again.
+#ifndef SF_LB_N
+#define SF_LB_N 1
+#endif
+    constexpr int SF_LB = SF_LB_N;
     excl = 0; pspill = 0;
     bool have_exit = ui == rf;
     pexit = 0;
