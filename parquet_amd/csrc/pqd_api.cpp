@@ -825,10 +825,6 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
 
     // levels, then everything that only needs them
     if (n_lreg) HIP_TRY(ctx, launch_levels(st, src, pl->lv, pl->lv_tile));
-    // the row offsets need the bitmaps of the level decode and nothing else: the longest kernel of this stream goes first
-    if (ctx->rows_first)
-        HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_rtile_owner, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
-                                 pl->d_row_tiles, pl->d_chunk_dyn));
     HIP_TRY(ctx, launch_page_scan(st, pl->d_chunks, n_chunks, pl->d_pages, n_pages, pl->d_page_dyn, pl->d_chunk_dyn, pl->d_status));
     if (n_sreg) {
         if (str_early && ctx->str_after_levels) {  // diagnostics: the marking pass behind the level decode, as it was when it took the page offsets from there
@@ -845,12 +841,17 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
         HIP_TRY(ctx, hipEventRecord(pl->ev_levels, st));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, pl->ev_levels, 0));
     }
+    // the row offsets need the bitmaps of the level decode and nothing else: the longest kernel of this stream goes first
+    // (the value index beside it when the strings' stream is idle, else behind it)
+    if (ctx->rows_first && !vidx_side)
+        HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_rtile_owner, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
+                                 pl->d_row_tiles, pl->d_chunk_dyn));
     HIP_TRY(ctx, launch_value_index(vidx_side ? ctx->stream2 : st, pl->d_chunks, pl->d_pages, pl->d_page_dyn, pl->d_vidx_pages,
                                     (u32)pl->vidx_pages.size(), pl->d_lvl_off));
     if (vidx_side) HIP_TRY(ctx, hipEventRecord(pl->ev_join, ctx->stream2));
     HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, pl->d_btile_owner, (u32)pl->bool_pages.size(), pl->n_btiles,
                               pl->d_chunks, pl->d_page_dyn, pl->d_status));
-    if (!ctx->rows_first)
+    if (!ctx->rows_first || vidx_side)
         HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_rtile_owner, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
                                  pl->d_row_tiles, pl->d_chunk_dyn));
     if (n_sreg) {
