@@ -25,6 +25,7 @@ struct pqd_ctx {
     bool str_fused = true;          // PQD_STR_PATH=twopass: every string chunk through the two passes (the single pass's fallback)
     bool str_giveup = false;        // PQD_STR_PATH=giveup: the single pass runs but finds every chunk given up already (tests of the hand-over)
     bool graph = false;             // PQD_GRAPH=1 replays chain batches as a captured HIP graph
+    bool levels_first = false;      // PQD_LEVELS_FIRST=1: diagnostics, see enqueue_run
     bool rows_first = true;         // PQD_ROWS_FIRST=0: the row offsets behind the value index, as they once were
     std::string err;
     u32 copy_grid = 0x7fffffffu;  // one block per 4 KiB tile; PQD_COPY_GRID caps it (then blocks grid-stride)
@@ -193,6 +194,8 @@ int pqd_create(int device, pqd_ctx** out) {
     if (sp) ctx->str_giveup = strcmp(sp, "giveup") == 0;
     const char* gr = getenv("PQD_GRAPH");
     if (gr) ctx->graph = atoi(gr) != 0;
+    const char* lf = getenv("PQD_LEVELS_FIRST");
+    if (lf) ctx->levels_first = atoi(lf) != 0;
     const char* rf = getenv("PQD_ROWS_FIRST");
     if (rf) ctx->rows_first = atoi(rf) != 0;
     *out = ctx;
@@ -621,7 +624,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_lvpos = ap.take((size_t)pl->n_lvtiles * 8), o_lvval = ap.take((size_t)pl->n_lvtiles * 8);  // hand-off granules
     // strings, single pass: a status word per tile, a flag per chunk, one flag for the batch
     const size_t o_sstat = ap.take(pl->sunit_region.size() * 8);
-    const size_t o_sfail = ap.take(pl->str_chunk_prefix.size() * 4), o_sany = ap.take(16);
+    const size_t o_sfail = ap.take(pl->str_chunk_prefix.size() * 4), o_srep = ap.take(pl->str_chunk_prefix.size() * 4), o_sany = ap.take(16);
     const size_t zero_end = ap.total;
     // the copy segment tables depend on output addresses → placed last, sized now
     size_t n_segs = 0;
@@ -738,6 +741,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     if (ctx->str_fused) {
         pl->schain.str_stat = (u64*)(A + o_sstat);
         pl->schain.str_failed = (u32*)(A + o_sfail);
+        pl->schain.str_repairs = (u32*)(A + o_srep);
         pl->schain.str_any = (u32*)(A + o_sany);
         pl->schain.n_units = (u32)pl->sunit_region.size();
         pl->schain.units = (StrUnit*)(A + o_suo);
@@ -806,6 +810,8 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     const bool str_early = ctx->overlap && n_lreg && n_sreg;
     const bool copy_side = ctx->overlap && pl->n_copy_blocks && (n_lreg || n_sreg);
     hipStream_t cst = copy_side ? ctx->stream3 : st, sst = str_early ? ctx->stream2 : st;
+    // diagnostics (PQD_LEVELS_FIRST=1): the level decode alone, the other streams start behind it
+    if (ctx->levels_first && n_lreg) HIP_TRY(ctx, launch_levels(st, src, pl->lv, pl->lv_tile));
     if (copy_side || str_early) HIP_TRY(ctx, hipEventRecord(pl->ev_fork, st));
     if (copy_side) HIP_TRY(ctx, hipStreamWaitEvent(cst, pl->ev_fork, 0));
     if (ev_c0) HIP_TRY(ctx, hipEventRecord(ev_c0, cst));
@@ -824,7 +830,7 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     }
 
     // levels, then everything that only needs them
-    if (n_lreg) HIP_TRY(ctx, launch_levels(st, src, pl->lv, pl->lv_tile));
+    if (n_lreg && !ctx->levels_first) HIP_TRY(ctx, launch_levels(st, src, pl->lv, pl->lv_tile));
     HIP_TRY(ctx, launch_page_scan(st, pl->d_chunks, n_chunks, pl->d_pages, n_pages, pl->d_page_dyn, pl->d_chunk_dyn, pl->d_status));
     if (n_sreg) {
         if (str_early && ctx->str_after_levels) {  // diagnostics: the marking pass behind the level decode, as it was when it took the page offsets from there

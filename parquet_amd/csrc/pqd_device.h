@@ -161,6 +161,7 @@ struct ChainArgs {
     u64* str_stamps;          // diagnostics only (else null): SF_STAMPS wall-clock stamps (100 MHz) per workgroup of k_str_fused
     u32* str_failed;          // one word per BYTE_ARRAY chunk, zero before every run: set = the chunk goes through the two passes
     u32* str_any;             // one word, zero before every run: set when any chunk was given up
+    u32* str_repairs;         // one word per BYTE_ARRAY chunk, zero before every run: tiles of the chunk that were walked string by string
 };
 hipError_t launch_chain(hipStream_t st, int kind, const u8* src, const ChainArgs& a, RunRec* run_tbl, u32* otile_first_run,
                         const PageDyn* page_dyn, int* status, int phase);

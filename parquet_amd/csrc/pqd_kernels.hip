@@ -1116,6 +1116,15 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
 #ifndef SF_EXP
 #define SF_EXP 0
 #endif
+// The guess uses the candidates of the two passes (a length below STR_CAND_MAX that fits in the page).  A bound of 64 KiB
+// (one position in 65536 of random bytes a candidate instead of one in 4096), with candidates that claim an empty string
+// dropped unless a candidate follows 4 bytes on (chars that begin with a zero byte make the position behind a true start
+// a candidate too), was tried: contents of random bytes or UTF-16-like text still mislead the guess often enough for the
+// chunk to be given up (a length of 256 or more in front of a zero byte cannot be told from a short one a byte later
+// without following both), and strings of 64 KiB to 1 MiB, which the guess then does not see, were given up as well.
+constexpr u32 SF_CAND_MAX = STR_CAND_MAX;
+static_assert(SF_CAND_MAX % 65536 == 0, "sf_small_mask compares the upper half of the length");
+static __device__ __forceinline__ u32 sf_cand_room(int r) { return str_cand_room(r); }
 constexpr u64 SF_AGG = 1, SF_INCL = 2, SF_FAIL = 3;  // state of a unit's status word (0: nothing published yet)
 constexpr u32 SF_PASS = 0xFFFFFFFDu;       // exit of a tile (unit) in which no string starts: the exit of the one before it
 constexpr u32 SF_CNT_MAX = (1u << 28) - 1; // strings of a chunk that the status word can count
@@ -1143,7 +1152,7 @@ static __device__ __forceinline__ u32 sf_wave_scan(u32 v) {
 }
 static __device__ __forceinline__ u32 sf_wave_sum(u32 v) { return (u32)__builtin_amdgcn_readlane((int)sf_wave_scan(v), 63); }
 // Bit k of the result: the four bytes at byte k of the lane's 36-byte window W (nine little-endian words) are a number
-// below 2^20, i.e. the 16-bit number at byte k + 2 is below 16.  Those lie in the halves of W's words (even k) and of
+// below SF_CAND_MAX, i.e. the 16-bit number at byte k + 2 is below SF_CAND_MAX / 65536.  Those lie in the halves of W's words (even k) and of
 // the words shifted by one byte (odd k); one compare on a half word and one add-with-carry (c = 2 c + carry) per position.
 static __device__ __forceinline__ u32 sf_small_mask(const u32 (&W)[9]) {
     u32 y[9];
@@ -1151,7 +1160,7 @@ static __device__ __forceinline__ u32 sf_small_mask(const u32 (&W)[9]) {
     for (int d = 0; d < 8; d++) y[d] = __builtin_amdgcn_alignbit(W[d + 1], W[d], 8);  // bytes 4d+1 .. 4d+4
     y[8] = W[8] >> 8;                                                                // bytes 33 .. 35
     u32 c = 0;
-    const u32 k16 = 16;
+    const u32 k16 = SF_CAND_MAX >> 16;
 #pragma unroll
     for (int d = 7; d >= 0; d--)  // positions 4d+3, 4d+2, 4d+1, 4d: half words at bytes 4d+5, 4d+4, 4d+3, 4d+2
         asm("v_cmp_gt_u32_sdwa vcc, %[k], %[yn] src0_sel:DWORD src1_sel:WORD_0\n\t"
@@ -1264,10 +1273,11 @@ static __device__ __forceinline__ void sf_stage_tail(const u8* rsrc, u32 L, u32 
 __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__ src_base, const Region* __restrict__ regions,
                                                           const StrUnit* __restrict__ units,
                                                           u64* __restrict__ ustat, u32* __restrict__ chunk_failed,
+                                                          u32* __restrict__ chunk_repairs,
                                                           u32* __restrict__ any_failed, u64* __restrict__ stamps) {
     constexpr u32 BAD = 0xFFFFFFFFu;  // s_cnt of a tile whose guess did not prove itself
     constexpr u32 NW = SF_SUB / 4;    // words per lane
-    constexpr u32 NONE = 0xFFFFu;     // no start (positions are below SF_T + 4 + STR_CAND_MAX only where compared with this)
+    constexpr u32 NONE = 0xFFFFFFu;   // no start
     static_assert(SF_SUB == 64 && SF_TPU == SF_WAVES, "one 64-bit mask per lane, one tile per wave");
 #define SF_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(u64)blockIdx.x * SF_STAMPS + (i)] = wall_clock64(); } while (0)
     SF_STAMP(0);
@@ -1339,8 +1349,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
     if (on) {
         const u32 la = (u32)__builtin_amdgcn_readlane((int)nw, 63);  // the four bytes behind the tile
         u64 C;
-        static_assert(STR_CAND_MAX == 1u << 20, "sf_small_mask tests for lengths below 2^20");
-        if (rem >= SF_T + 4 + STR_CAND_MAX) {  // every position of the tile has STR_CAND_MAX bytes of page behind it
+        if (rem >= SF_T + 4 + SF_CAND_MAX) {  // every position of the tile has SF_CAND_MAX bytes of page behind it
             const u32 W_lo[9] = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]};
             const u32 W_hi[9] = {w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15], nw};
             C = sf_small_mask(W_lo) | ((u64)sf_small_mask(W_hi) << 32);
@@ -1351,12 +1360,12 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
             for (int k = 63; k >= 0; k--) {
                 const u32 hi_w = k / 4 + 1 < (int)NW ? w[(k / 4 + 1) & 15] : nw;
                 const u32 x = (k & 3) ? __builtin_amdgcn_alignbit(hi_w, w[k / 4], (k & 3) * 8) : w[k / 4];
-                c2[k >> 5] = (c2[k >> 5] << 1) | (u32)(x < str_cand_room(room0 - k));
+                c2[k >> 5] = (c2[k >> 5] << 1) | (u32)(x < sf_cand_room(room0 - k));
             }
             C = c2[0] | ((u64)c2[1] << 32);
         }
         u32 c_next = sf_lane_above((u32)C) & 1;
-        if (lane == 63) c_next = la < str_cand_room((int)rem - 3 - (int)SF_T);
+        if (lane == 63) c_next = la < sf_cand_room((int)rem - 3 - (int)SF_T);
         const u64 Sm = C & ~((C >> 1) | ((u64)c_next << 63));
         // the first guessed start in the lanes above mine (nf), and of the tile (ent): the lanes that hold a start, as a
         // mask, say which lane to ask
@@ -1519,6 +1528,10 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
                     s_cnt[t] = n;
                     s_spill[t] = spill;
                 }
+                // A walk takes some 15 us during which every unit behind this one in the chunk waits: worth it for the odd
+                // tile, not for contents that mislead the guess throughout (random bytes: 1.4 ms for 8 MB that the two
+                // passes decode in 0.2 ms).  More than one walk per 32 units of the chunk so far, and four: given up.
+                if (alive && nrep && atomicAdd(chunk_repairs + R.otile_base, nrep) + nrep > 4 + (ui - cf) / 32) alive = false;
                 uexit = pe;
             }
             alive = __shfl((u32)alive, 0) != 0;
@@ -2933,7 +2946,7 @@ hipError_t launch_str_fused(hipStream_t st, const u8* src, const ChainArgs& a, P
     if (a.n_regions == 0) return hipSuccess;
     if (a.n_units) {
         hipLaunchKernelGGL(k_str_fused, dim3(a.n_units), dim3(SF_THREADS), 0, st, src, a.regions, a.units,
-                           a.str_stat, a.str_failed, a.str_any, a.str_stamps);
+                           a.str_stat, a.str_failed, a.str_repairs, a.str_any, a.str_stamps);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_str_totals, dim3((a.n_regions + 63) / 64), dim3(64), 0, st, a.regions, a.n_regions, a.str_stat,

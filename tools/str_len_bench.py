@@ -42,7 +42,8 @@ def main():
         plan.sync()
         ms = (time.perf_counter() - t0) / 5 * 1e3
         bi, bo, _ = plan.bytes()
-        print("len %d..%d: %d strings, %.1f MB file, %.3f ms per run, %.1f GB/s" % (lo, hi, n, pf.size / 1e6, ms, (bi + bo) / ms / 1e6), flush=True)
+        print("len %d..%d: %d strings, %.1f MB file, %.3f ms per run, %.1f GB/s, chunks through the two passes: %d" %
+              (lo, hi, n, pf.size / 1e6, ms, (bi + bo) / ms / 1e6, plan.string_fallbacks()), flush=True)
         plan.close()
         N.decode.pqd_device_free(ctx.handle, d_src)
     ctx.close()
