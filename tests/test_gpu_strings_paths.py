@@ -103,3 +103,66 @@ def test_single_pass_repairs_a_lone_bad_tile():
         assert _fallbacks(ctx, buf) == (0, 1)
     finally:
         ctx.close()
+
+
+def _payload_with_prefixes_at(rng, targets, tail):
+    """Text strings whose length prefixes start exactly at the page positions `targets` (ascending), with strings of
+    8-32 bytes in between and `tail` more strings behind the last target."""
+    parts, pos = [], 0
+    for t in targets:
+        while t - pos > 120:
+            n = int(rng.integers(8, 33))
+            parts.append(bytes(rng.integers(97, 123, n, dtype=np.uint8)))
+            pos += 4 + n
+        n = t - pos - 4  # this string ends where the next prefix must start
+        assert n >= 0
+        parts.append(bytes(rng.integers(97, 123, n, dtype=np.uint8)))
+        pos = t
+    for _ in range(tail):
+        n = int(rng.integers(8, 33))
+        parts.append(bytes(rng.integers(97, 123, n, dtype=np.uint8)))
+    return parts
+
+
+@pytest.mark.parametrize("path", ["single", "twopass"])
+def test_length_prefixes_across_tile_and_unit_boundaries(path):
+    """A length prefix with 1, 2 or 3 of its bytes behind the end of a 4 KiB tile, of a 16 KiB unit and of the page's last
+    full tile; pages of odd sizes in one chunk, so that the chars of the later pages start at every alignment; a page
+    that ends a few bytes into a tile.  Against the oracle, on the single pass (which must keep the chunk) and on the two."""
+    from parquet_amd.writer import ParquetWriter
+    old = os.environ.get("PQD_STR_PATH")
+    if path == "twopass":
+        os.environ["PQD_STR_PATH"] = "twopass"
+    ctx = R.Context(0)
+    if path == "twopass":
+        if old is None:
+            del os.environ["PQD_STR_PATH"]
+        else:
+            os.environ["PQD_STR_PATH"] = old
+    try:
+        rng = np.random.default_rng(47)
+        cols = [Column("s", N.BYTE_ARRAY, [0])]
+        w = ParquetWriter(cols, stats=False)
+        w.begin_row_group()
+        all_parts, n_rows = [], 0
+        for page in range(4):
+            targets = []
+            for k, b in enumerate((4096, 8192, 12288, 16384, 20480, 32768, 49152, 65536 + 4096, 98304)):
+                targets.append(b - 1 - (k + page) % 3)        # 3, 2 or 1 bytes of the prefix lie behind the boundary
+            targets.append(98304 + 4096 * 3 + 4 + page)        # a prefix just behind a boundary
+            parts = _payload_with_prefixes_at(rng, targets, tail=1 + page)  # the page ends a few strings into a tile
+            parts.append(bytes(rng.integers(97, 123, page, dtype=np.uint8)))  # odd page sizes: every alignment of the next page's chars
+            payload = b"".join(len(x).to_bytes(4, "little") + x for x in parts)
+            w.write_raw_page(0, payload, len(parts))
+            all_parts += parts
+            n_rows += len(parts)
+        w.end_row_group(n_rows)
+        buf = w.finish()
+        o, g = H.check_file(buf, ctx)
+        assert bytes(g[(0, "s")]["chars"]) == b"".join(all_parts)
+        offs = np.asarray(g[(0, "s")]["offsets"])
+        assert offs[-1] == sum(len(x) for x in all_parts) and offs.size == n_rows + 1
+        if path == "single":
+            assert _fallbacks(ctx, buf) == (0, 1)
+    finally:
+        ctx.close()
