@@ -43,6 +43,12 @@ static __device__ __forceinline__ u32 find_owner(const u32* __restrict__ prefix,
 // dwordx4 at whatever alignment the page payload has in the file (gfx950 global loads need no
 // alignment).  Each wave instruction covers 1 KiB of contiguous memory on both sides.
 // =====================================================================================
+#ifndef CP_LOAD_NT
+#define CP_LOAD_NT 0
+#endif
+#ifndef CP_STORE_NT
+#define CP_STORE_NT 1
+#endif
 __global__ __launch_bounds__(CP_THREADS) void k_copy(const u8* __restrict__ src_base, const Seg* __restrict__ segs,
                                                      const u32* __restrict__ blk_prefix, const u32* __restrict__ blk_grp,
                                                      u32 n_segs, u32 n_blocks) {
@@ -74,12 +80,20 @@ __global__ __launch_bounds__(CP_THREADS) void k_copy(const u8* __restrict__ src_
 #pragma unroll
             for (int i = 0; i < CP_UNROLL; i++) {
                 const u32 k = tid + i * CP_THREADS;
+#if CP_LOAD_NT
                 if (k < n_units) r[i] = __builtin_nontemporal_load((const u32x4_u*)(sv + u0 + (u64)k * 16));
+#else
+                if (k < n_units) r[i] = *(const u32x4_u*)(sv + u0 + (u64)k * 16);
+#endif
             }
 #pragma unroll
             for (int i = 0; i < CP_UNROLL; i++) {
                 const u32 k = tid + i * CP_THREADS;
+#if CP_STORE_NT
                 if (k < n_units) __builtin_nontemporal_store(r[i], as_global((u32x4*)(dv + u0 + (u64)k * 16)));
+#else
+                if (k < n_units) *as_global((u32x4*)(dv + u0 + (u64)k * 16)) = r[i];
+#endif
             }
             // head [v_lo, u0) and tail [u1, v_hi): fewer than 16 bytes each
             if (tid < (u32)(u0 - v_lo)) *as_global(dv + v_lo + tid) = sv[v_lo + tid];
@@ -1116,6 +1130,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_str_mark(const u8* __restrict__ 
 #ifndef SF_EXP
 #define SF_EXP 0
 #endif
+#ifndef SF_NT_STORE
+#define SF_NT_STORE 1
+#endif
 // The guess uses the candidates of the two passes (a length below STR_CAND_MAX that fits in the page).  A bound of 64 KiB
 // (one position in 65536 of random bytes a candidate instead of one in 4096), with candidates that claim an empty string
 // dropped unless a candidate follows 4 bytes on (chars that begin with a zero byte make the position behind a true start
@@ -1603,7 +1620,11 @@ __global__ __launch_bounds__(SF_THREADS) void k_str_fused(const u8* __restrict__
 #pragma unroll 1
     for (u32 c0 = head_end + lane * 16; c0 < tail_lo; c0 += 64 * 16) {
         const u32* const sp = (const u32*)(stage + c0);  // 4-byte aligned
+#if SF_NT_STORE
+        __builtin_nontemporal_store(u32x4{sp[0], sp[1], sp[2], sp[3]}, as_global((u32x4*)(cd - pd0 + c0)));
+#else
         if (!(SF_EXP & 2)) *as_global((u32x4*)(cd - pd0 + c0)) = u32x4{sp[0], sp[1], sp[2], sp[3]};
+#endif
     }
     if (lane < 16) { if (pd0 + lane < head_end) *as_global(cd + lane) = stage[pd0 + lane]; }
     else if (lane < 32) { const u32 b = tail_lo + lane - 16; if (b < n_stg) *as_global(cd + (b - pd0)) = stage[b]; }

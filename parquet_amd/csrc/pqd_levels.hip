@@ -38,6 +38,9 @@
 #include "pqd_device.h"
 #include "pqd_rle.h"
 
+#ifndef LV_NT_STORE
+#define LV_NT_STORE 1
+#endif
 namespace pqd {
 #if PQD_LV_TILE_BYTES != 8192
 namespace lv4k {  // the second build of the kernel keeps its names apart
@@ -818,7 +821,11 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
             } else v = lv_dense16(dense, (u32)((int)LV_DENSE_BIAS + ((int)v0 - (int)mis) * (int)width), width);
             u8* const dst = dbase + v0;
             const u64 acc_lo = v.x | ((u64)v.y << 32), acc_hi = v.z | ((u64)v.w << 32);
+#if LV_NT_STORE
+            if (hi_v - lo_v == 16) __builtin_nontemporal_store(v, as_global((u32x4*)dst));
+#else
             if (hi_v - lo_v == 16) *as_global((u32x4*)dst) = v;
+#endif
             else for (u32 k = lo_v - v0; k < hi_v - v0; k++) *as_global(dst + k) = (u8)(k < 8 ? acc_lo >> (8 * k) : acc_hi >> (8 * (k - 8)));
             if (counting) {
                 // bit k: value k of the block equals max_def (fields.go:220-228); bits [k0, k1) are mine
