@@ -28,10 +28,57 @@ struct pqd_ctx {
     bool levels_first = false;      // PQD_LEVELS_FIRST=1: diagnostics, see enqueue_run
     bool rows_first = true;         // PQD_ROWS_FIRST=0: the row offsets behind the value index, as they once were
     std::string err;
+    // Device blocks of destroyed plans, kept for the next plan of this context: a reader makes one plan per row group, all
+    // of about the same size, and hipMalloc / hipFree cost a millisecond a pair and synchronise the device.
+    struct Block { void* p; size_t bytes; };
+    std::vector<Block> pool;                 // free blocks (at most POOL_MAX)
+    std::vector<Block> live;                 // blocks handed out by pool_alloc
+    static constexpr size_t POOL_MAX = 4;
     u32 copy_grid = 0x7fffffffu;  // one block per 4 KiB tile; PQD_COPY_GRID caps it (then blocks grid-stride)
 };
 
 namespace {
+
+// a block of at least `bytes` from the context's pool (the smallest that fits and is not more than twice as large), else
+// from hipMalloc; null on failure
+void* pool_alloc(pqd_ctx* ctx, size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    size_t best = ctx->pool.size();
+    for (size_t i = 0; i < ctx->pool.size(); i++)
+        if (ctx->pool[i].bytes >= bytes && ctx->pool[i].bytes / 2 <= bytes && (best == ctx->pool.size() || ctx->pool[i].bytes < ctx->pool[best].bytes))
+            best = i;
+    pqd_ctx::Block b{nullptr, bytes};
+    if (best < ctx->pool.size()) {
+        b = ctx->pool[best];
+        ctx->pool.erase(ctx->pool.begin() + (long)best);
+    } else if (hipMalloc(&b.p, bytes) != hipSuccess) {
+        // memory may be held by the pool: give it back and try once more
+        for (auto& f : ctx->pool) (void)hipFree(f.p);
+        ctx->pool.clear();
+        if (hipMalloc(&b.p, bytes) != hipSuccess) return nullptr;
+    }
+    ctx->live.push_back(b);
+    return b.p;
+}
+// gives a block of pool_alloc back; the caller has waited for all work that uses it
+void pool_release(pqd_ctx* ctx, void* p) {
+    if (!p) return;
+    for (size_t i = 0; i < ctx->live.size(); i++)
+        if (ctx->live[i].p == p) {
+            const pqd_ctx::Block b = ctx->live[i];
+            ctx->live.erase(ctx->live.begin() + (long)i);
+            if (ctx->pool.size() >= pqd_ctx::POOL_MAX) {  // the smallest goes
+                size_t m = 0;
+                for (size_t k = 1; k < ctx->pool.size(); k++) if (ctx->pool[k].bytes < ctx->pool[m].bytes) m = k;
+                if (ctx->pool[m].bytes >= b.bytes) { (void)hipFree(b.p); return; }
+                (void)hipFree(ctx->pool[m].p);
+                ctx->pool.erase(ctx->pool.begin() + (long)m);
+            }
+            ctx->pool.push_back(b);
+            return;
+        }
+    (void)hipFree(p);  // not from the pool
+}
 
 int bits_len(unsigned v) { int n = 0; while (v) { n++; v >>= 1; } return n; }  // math/bits.Len
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -205,6 +252,7 @@ int pqd_create(int device, pqd_ctx** out) {
 void pqd_destroy(pqd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    for (auto& b : ctx->pool) (void)hipFree(b.p);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
@@ -251,8 +299,8 @@ void pqd_plan_destroy(pqd_plan* pl) {
     if (!pl) return;
     (void)hipSetDevice(pl->ctx->device);
     (void)hipStreamSynchronize(pl->ctx->stream);
-    if (pl->arena) (void)hipFree(pl->arena);
-    if (pl->owned_src) (void)hipFree(pl->owned_src);
+    pool_release(pl->ctx, pl->arena);      // the stream has been waited for: nothing uses the blocks any more
+    pool_release(pl->ctx, pl->owned_src);
     for (auto& set : pl->ev)
         for (hipEvent_t e : set)
             if (e) (void)hipEventDestroy(e);
@@ -641,8 +689,8 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_segg = ap.take((size_t)(max_blocks / CP_GRP + 2) * 4);  // segment of every CP_GRP-th block
 
     pl->arena_bytes = ap.total;
-    hipError_t e = hipMalloc((void**)&pl->arena, pl->arena_bytes);
-    if (e != hipSuccess) return fail(ctx, PQD_E_NOMEM, "hipMalloc of the plan arena failed", e);
+    pl->arena = (u8*)pool_alloc(ctx, pl->arena_bytes);
+    if (!pl->arena) return fail(ctx, PQD_E_NOMEM, "hipMalloc of the plan arena failed");
     u8* A = pl->arena;
 
     // patch pointers
@@ -1124,9 +1172,13 @@ int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks, cons
             total += align_up((size_t)blocks[i].decoded_len + 16, 256);
         }
     }
-    u8* dsrc = (u8*)pqd_device_alloc(ctx, total);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    u8* dsrc = (u8*)pool_alloc(ctx, total + 64);
     if (!dsrc) return fail(ctx, PQD_E_NOMEM, "device allocation for the source failed");
-    int rc = span ? pqd_copy_to_device(ctx, dsrc, host, span) : PQD_OK;
+    // queued, not waited for: the plan is made on the host while the bytes travel (from pageable memory the call
+    // returns when the bytes have left the caller's buffer), and everything that reads them is queued behind the copy
+    int rc = PQD_OK;
+    if (span && hipMemcpyAsync(dsrc, host, span, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, PQD_E_HIP, "upload of the page bytes failed");
     if (!rc && !blocks.empty()) {
         rc = pqd_snappy_decode(ctx, blocks.data(), blocks.size(), dsrc, span, dsrc + file_area, total - file_area);
         // the level block sizes of decoded pages can only be read on the device
@@ -1143,7 +1195,8 @@ int pqd_decode(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks, cons
     // the planner reads level block lengths of uncompressed pages from the host bytes: the same range, the same offsets
     if (!rc) rc = pqd_plan_create(ctx, cv.data(), n_chunks, pv.data(), n_pages, host, total, &pl);
     if (rc) {
-        pqd_device_free(ctx, dsrc);
+        (void)hipStreamSynchronize(ctx->stream);
+        pool_release(ctx, dsrc);
         return rc;
     }
     pl->h2d_bytes = (int64_t)span;
