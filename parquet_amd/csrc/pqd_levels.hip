@@ -41,6 +41,9 @@
 #ifndef LV_NT_STORE
 #define LV_NT_STORE 1
 #endif
+#ifndef LV_DIRECT_OR
+#define LV_DIRECT_OR 1
+#endif
 namespace pqd {
 #if PQD_LV_TILE_BYTES != 8192
 namespace lv4k {  // the second build of the kernel keeps its names apart
@@ -732,10 +735,20 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
                         }
                         if (nb_all < 64) bits &= (1ull << nb_all) - 1;
                         if (bits) {  // zeros are there already
+#if LV_DIRECT_OR
+                            // straight into the stream: up to three words, each with one LDS atomic
+                            const u32 j0 = qb0 >> 5, sh = qb0 & 31;
+                            const u64 lo64 = bits << sh;
+                            const u32 top = sh ? (u32)(bits >> (64 - sh)) : 0;
+                            if ((u32)lo64) atomicOr(&dense[j0], (u32)lo64);
+                            if ((u32)(lo64 >> 32)) atomicOr(&dense[j0 + 1], (u32)(lo64 >> 32));
+                            if (top) atomicOr(&dense[j0 + 2], top);
+#else
                             acc_seek(qb0);
                             const u32 n1 = nb_all < 32 ? nb_all : 32;
                             append((u32)bits, n1);
                             if (nb_all > 32) append((u32)(bits >> 32), nb_all - 32);
+#endif
                         }
                     } else if (vals && ra < W1 && rb > W0) {
                         if (dq0 == ERR_POS) { dq0 = q; dra0 = ra; }
