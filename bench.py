@@ -558,11 +558,16 @@ def main():
         if world == 1 and not args.no_extras and args.workload == "mixed":
             # the single-config workloads on smaller files, same run, same checks
             extras = {}
-            for wl, (pg, rgs) in (("flat", (32, 2)), ("optint", (32, 2)), ("optstr", (16, 2)), ("nested", (16, 2)), ("wide", (2, 2))):
+            # two shapes each: a file of two row groups (a step of 0.15-0.6 ms, where the hand-over chains inside a level block
+            # or a column chunk are as long as the step) and one of 16-32 row groups, where the kernels run at their rate
+            for key, wl, (pg, rgs) in (("flat", "flat", (32, 2)), ("optint", "optint", (32, 2)), ("optstr", "optstr", (16, 2)),
+                                       ("nested", "nested", (16, 2)), ("wide", "wide", (2, 2)),
+                                       ("optint_32rg", "optint", (8, 32)), ("optstr_32rg", "optstr", (4, 32)),
+                                       ("nested_32rg", "nested", (4, 32)), ("wide_16rg", "wide", (2, 16))):
                 e = Loaded(ctx, wl, list(range(rgs)), pg, args.rows_per_page)
                 el, sm, _ = timed(e, 50, 3)
                 bi, bo, _ = e.plan.bytes()
-                extras[wl] = {"value": round((bi + bo) * 50 / el / 1e9, 1), "unit": "GB/s", "ms_per_step": round(el / 50 * 1e3, 4),
+                extras[key] = {"value": round((bi + bo) * 50 / el / 1e9, 1), "unit": "GB/s", "ms_per_step": round(el / 50 * 1e3, 4),
                               "roofline_frac": round((bi + bo) / (sm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "shape": "%d pages/chunk, %d row groups" % (pg, rgs)}
                 e.close()
