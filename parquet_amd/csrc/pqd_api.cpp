@@ -863,6 +863,7 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     if (copy_side || str_early) HIP_TRY(ctx, hipEventRecord(pl->ev_fork, st));
     if (copy_side) HIP_TRY(ctx, hipStreamWaitEvent(cst, pl->ev_fork, 0));
     if (ev_c0) HIP_TRY(ctx, hipEventRecord(ev_c0, cst));
+    if (!getenv("PQD_SKIP_COPY"))  // diagnostics: what the step takes without the gather
     HIP_TRY(ctx, launch_copy(cst, src, pl->d_segs, pl->d_seg_blk_prefix, pl->d_seg_grp, (u32)pl->segs.size(), pl->n_copy_blocks, ctx->copy_grid));
     if (ev_c1) HIP_TRY(ctx, hipEventRecord(ev_c1, cst));
     if (copy_side) HIP_TRY(ctx, hipEventRecord(pl->ev_join_copy, cst));

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostics: phase timeline of k_str_fused (strings in one pass) on one bench workload (runs on the GPU box).
-usage: python tools/str_timeline.py [workload] [pages or row groups]"""
+usage: python tools/str_timeline.py [workload] [pages (mixed: row groups)] [row groups]"""
 import ctypes as C
 import os
 import sys
@@ -24,7 +24,7 @@ def main():
     if workload == "mixed":
         buf, _ = bench.build_file(workload, list(range(k)), 1, 1_000_000)
     else:
-        buf, _ = bench.build_file(workload, [0, 1], k, 1_000_000)
+        buf, _ = bench.build_file(workload, list(range(int(sys.argv[3]) if len(sys.argv) > 3 else 2)), k, 1_000_000)
     pf = R.ParquetFile(buf)
     ctx = R.Context(0)
     chunks, nc, pgs, npg = pf.descriptors(0, pf.num_row_groups)
