@@ -837,7 +837,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
 
 // Queues one run of the plan on the decoder's streams.  ev_c0 / ev_c1 bracket the PLAIN value gather when
 // given; under graph capture they are absent and a plain join event orders the two streams.
-static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t ev_c1) {
+static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t ev_c1, bool one_stream = false) {
     pqd_ctx* ctx = pl->ctx;
     hipStream_t st = ctx->stream;
     const u32 n_chunks = (u32)pl->chunks.size(), n_pages = (u32)pl->pages.size();
@@ -855,8 +855,9 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     // the gather runs beside them on a stream of its own.  The strings (exit tables, hops, totals, marking pass)
     // need nothing from the levels either and go to another side stream; only the final comparison of their
     // counts with the levels' waits.  Levels, page scan, bools and row offsets stay on the main stream.
-    const bool str_early = ctx->overlap && n_lreg && n_sreg;
-    const bool copy_side = ctx->overlap && pl->n_copy_blocks && (n_lreg || n_sreg);
+    const bool overlap = ctx->overlap && !one_stream;
+    const bool str_early = overlap && n_lreg && n_sreg;
+    const bool copy_side = overlap && pl->n_copy_blocks && (n_lreg || n_sreg);
     hipStream_t cst = copy_side ? ctx->stream3 : st, sst = str_early ? ctx->stream2 : st;
     // diagnostics (PQD_LEVELS_FIRST=1): the level decode alone, the other streams start behind it
     if (ctx->levels_first && n_lreg) HIP_TRY(ctx, launch_levels(st, src, pl->lv, pl->lv_tile));
@@ -891,7 +892,7 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
     }
     // The value index needs the page scan only.  In a batch without strings their stream is idle: the index runs there,
     // beside the bools and the row offsets (nested columns: three launches shorter on the main stream).
-    const bool vidx_side = ctx->overlap && !n_sreg && n_lreg && !pl->row_chunks.empty();
+    const bool vidx_side = overlap && !n_sreg && n_lreg && !pl->row_chunks.empty();
     if (vidx_side) {
         HIP_TRY(ctx, hipEventRecord(pl->ev_levels, st));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, pl->ev_levels, 0));
@@ -935,7 +936,11 @@ int pqd_plan_run(pqd_plan* pl, const void* src_device) {
         if (!pl->gexec || pl->gsrc != src) {
             if (pl->gexec) { (void)hipGraphExecDestroy(pl->gexec); pl->gexec = nullptr; }
             HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            const int rc = enqueue_run(pl, src, nullptr, nullptr);
+            // One stream under capture: a graph with parallel branches runs them on streams of the runtime's own, on top of
+            // this context's three, and more streams than hardware queues (four per process here) share queues: replays of
+            // such a graph were seen to take seconds (6-110 s for three replays of a 100 us batch, no device error, fast
+            // again under a profiler that serialises kernels).  A linear graph has no such branches.
+            const int rc = enqueue_run(pl, src, nullptr, nullptr, true);
             hipGraph_t g = nullptr;
             const hipError_t e = hipStreamEndCapture(st, &g);
             if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
