@@ -587,6 +587,38 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     // workgroups take super-tiles in this order: super-tile t of every block before super-tile t + 1 of any, so
     // the one a workgroup waits for was always taken earlier, and the chains of all blocks advance side by side
     std::stable_sort(pl->lv_order.begin(), pl->lv_order.end(), [](const LvTile& x, const LvTile& y) { return x.index < y.index; });
+    const int lv_balance = getenv("PQD_LV_BALANCE") ? atoi(getenv("PQD_LV_BALANCE")) : 1;  // 0: off, 2: also for a few blocks (tests)
+    if (lv_balance == 2 || (lv_balance == 1 && pl->lregions.size() >= 64)) {  // fewer blocks would leave XCDs without any
+        // Workgroups are dealt to the eight XCDs in turn, so position p of the order runs on XCD p % 8.  Every block is given
+        // to one XCD (its hand-overs then stay inside that XCD, which measured faster than blocks that go round the XCDs)
+        // and the blocks are shared out so that every XCD gets the same number of super-tiles: in the order of the file a
+        // batch of six level blocks per row group, three of them five times as long as the others, put 1.7 times the
+        // super-tiles on the odd XCDs, and every other kernel's share of those XCDs ran late with them.  Longest blocks
+        // first, each to the XCD with the least so far; positions that stay empty hold a workgroup that returns at once.
+        constexpr u32 NX = 8;
+        const u32 nreg = (u32)pl->lregions.size();
+        std::vector<u32> n_sup(nreg, 0), xcd(nreg, 0), by_len(nreg);
+        for (const LvTile& t : pl->lv_order) n_sup[t.region]++;
+        for (u32 r = 0; r < nreg; r++) by_len[r] = r;
+        std::stable_sort(by_len.begin(), by_len.end(), [&](u32 a, u32 b) { return n_sup[a] > n_sup[b]; });
+        u64 load[NX] = {};
+        for (u32 r : by_len) {
+            u32 best = 0;
+            for (u32 x = 1; x < NX; x++) if (load[x] < load[best]) best = x;
+            xcd[r] = best;
+            load[best] += n_sup[r];
+        }
+        std::vector<LvTile> q[NX];
+        for (const LvTile& t : pl->lv_order) q[xcd[t.region]].push_back(t);  // keeps (index, region) order inside a queue
+        size_t longest = 0;
+        for (u32 x = 0; x < NX; x++) longest = std::max(longest, q[x].size());
+        std::vector<LvTile> order(longest * NX, LvTile{ERR_POS, 0});
+        for (u32 x = 0; x < NX; x++)
+            for (size_t i = 0; i < q[x].size(); i++) order[i * NX + x] = q[x][i];
+        while (!order.empty() && order.back().region == ERR_POS) order.pop_back();
+        if (order.size() > 0x7fffffffull) return fail(ctx, PQD_E_UNSUPPORTED, "batch too large for 32-bit tile indices");
+        pl->lv_order.swap(order);
+    }
     pl->n_stiles_chain = pl->stile_chain_prefix.back();
     for (size_t r = 0; r < pl->sregions.size(); r++)
         pl->stile_region.insert(pl->stile_region.end(), pl->stile_chain_prefix[r + 1] - pl->stile_chain_prefix[r], (u32)r);
@@ -654,7 +686,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     const size_t o_rtiles = ap.take((size_t)pl->n_rtiles * sizeof(RowTile));
     const size_t o_cdyn = ap.take(n_chunks * sizeof(ChunkDyn));
     const bool lv_stamps = getenv("PQD_LV_STAMPS") != nullptr;  // diagnostics: per-workgroup phase stamps of k_levels
-    const size_t o_lvst = lv_stamps ? ap.take((size_t)pl->n_lvtiles * LV_STAMPS * 8) : 0;
+    const size_t o_lvst = lv_stamps ? ap.take(pl->lv_order.size() * LV_STAMPS * 8) : 0;  // a record per position of the order
     const bool str_stamps = getenv("PQD_STR_STAMPS") != nullptr;  // diagnostics: per-workgroup phase stamps of k_str_fused
     const size_t o_sfst = str_stamps ? ap.take(pl->sunit_region.size() * SF_STAMPS * 8) : 0;
     // reset to 0xFF every run
@@ -785,7 +817,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
     pl->ff_begin = A + o_ff; pl->ff_bytes = ff_end - o_ff;
     pl->zero_begin = A + o_zero; pl->zero_bytes = zero_end - o_zero;
 
-    pl->lv = LvArgs{pl->d_lregions, (const LvTile*)(A + o_lvo), pl->n_lvtiles, (u64*)(A + o_lvpos), (u64*)(A + o_lvval),
+    pl->lv = LvArgs{pl->d_lregions, (const LvTile*)(A + o_lvo), (u32)pl->lv_order.size(), (u64*)(A + o_lvpos), (u64*)(A + o_lvval),
                     (u32*)(A + o_lvticket), pl->d_page_dyn, pl->d_status, lv_stamps ? (u64*)(A + o_lvst) : nullptr};
     pl->schain = ChainArgs{pl->d_sregions, pl->d_stile_chain_prefix, pl->d_sgroup_prefix, (u32)pl->sregions.size(), pl->n_stiles_chain,
                            n_sgroups, pl->d_sexit, pl->d_sgexit, pl->d_stile_entry, pl->d_sgroup_entry, pl->d_stotals, A + o_scp,
@@ -1112,7 +1144,7 @@ int64_t pqd_plan_debug_stamps(pqd_plan* pl, void* dst, size_t cap) {
         return (int64_t)n;
     }
     if (!pl || !pl->lv.stamps) return 0;
-    const size_t n = (size_t)pl->n_lvtiles * LV_STAMPS * 8;
+    const size_t n = pl->lv_order.size() * LV_STAMPS * 8;  // positions without a super-tile stay zero
     if (n > cap || !dst) return PQD_E_ARG;
     HIP_TRY(pl->ctx, hipSetDevice(pl->ctx->device));
     HIP_TRY(pl->ctx, hipMemcpy(dst, pl->lv.stamps, n, hipMemcpyDeviceToHost));

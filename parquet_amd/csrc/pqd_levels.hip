@@ -264,8 +264,9 @@ __global__ __launch_bounds__(LV_THREADS) void k_levels(const u8* __restrict__ sr
     // 12 ns each for all workgroups of the launch one after the other).
     const u32 ticket = blockIdx.x;
     if (ticket >= a.n_tiles) return;
-    LV_STAMP(0);
     const LvTile ot = a.order[ticket];
+    if (ot.region == ERR_POS) return;  // a position of the order that holds no super-tile
+    LV_STAMP(0);
     const Region R = a.regions[ot.region];
     const u32 L = R.len, width = R.width, j = ot.index;
     const u32 sb = j * LV_T, se = sb + LV_T;      // a level block is shorter than 2^31 bytes

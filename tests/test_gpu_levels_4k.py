@@ -97,3 +97,23 @@ def test_a_large_batch_selects_the_small_tiles_by_itself(ctx):
     finally:
         N.decode.pqd_device_free(ctx.handle, d_src)
         plan.close()
+
+
+@pytest.mark.parametrize("tile", ["4096", "8192"])
+def test_level_blocks_shared_out_over_the_xcds(ctx, monkeypatch, tile):
+    """The launch order of a large batch gives every level block to one XCD and leaves positions without a super-tile
+    (PQD_LV_BALANCE=2 asks for that order whatever the number of blocks): same results on optional, nested and fuzzed
+    inputs, blocks of one and of many super-tiles, both builds."""
+    monkeypatch.setenv("PQD_LV_TILE", tile)
+    monkeypatch.setenv("PQD_LV_BALANCE", "2")
+    rng = np.random.default_rng(47)
+    cols = [Column("a", N.INT32, [1]), Column("s", N.BYTE_ARRAY, [1]), Column("b", N.BOOLEAN, [1]),
+            Column("friends.id", N.INT32, [2, 0]), Column("friends.age", N.INT32, [2, 1]),
+            Column("a.b.c.d.e", N.INT32, [1, 2, 1, 2, 1])]
+    for p_null in (0.1, 0.5):
+        H.check_file(H.build_file(cols, 90000, 30000, 17000, rng, p_null=p_null, str_len=(0, 12)), ctx)
+    for seed in (2, 3):
+        P.test_fuzz_level_blocks_through_pages(ctx, seed)
+        P.test_fuzz_whole_files(ctx, seed)
+    P.test_corrupt_pages_return_errors_not_crashes(ctx)
+    P.test_surplus_levels_equal_to_max_def_are_refused(ctx)
