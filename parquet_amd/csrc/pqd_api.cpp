@@ -158,6 +158,7 @@ struct pqd_plan {
     hipEvent_t ev[EV_RING][4] = {};
     hipEvent_t ev_fork = nullptr;  // orders the value gather's side stream after the run start
     hipEvent_t ev_join = nullptr;  // ... the strings' marking pass after their first pass
+    hipEvent_t ev_vidx = nullptr;  // ... the value index on a side stream
     hipEvent_t ev_join_copy = nullptr;  // ... and the run's end after the gather
     hipEvent_t ev_levels = nullptr;     // the page scan is done: value index on the side stream; diagnostics (PQD_STR_AFTER_LEVELS)
     hipGraphExec_t gexec = nullptr;  // captured run (see pqd_plan_run)
@@ -307,6 +308,7 @@ void pqd_plan_destroy(pqd_plan* pl) {
             if (e) (void)hipEventDestroy(e);
     if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
     if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
+    if (pl->ev_vidx) (void)hipEventDestroy(pl->ev_vidx);
     if (pl->ev_join_copy) (void)hipEventDestroy(pl->ev_join_copy);
     if (pl->ev_levels) (void)hipEventDestroy(pl->ev_levels);
     if (pl->gexec) (void)hipGraphExecDestroy(pl->gexec);
@@ -865,6 +867,7 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         for (hipEvent_t& e : set) HIP_TRY(ctx, hipEventCreate(&e));
     HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_vidx, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_join_copy, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&pl->ev_levels, hipEventDisableTiming));
     pl->h_chunk_dyn.resize(n_chunks);
@@ -928,21 +931,30 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
         HIP_TRY(ctx, launch_chain(sst, KIND_STRINGS, src, pl->schain, nullptr, nullptr, pl->d_str_pd, pl->d_status, 1));
         if (str_early) HIP_TRY(ctx, hipEventRecord(pl->ev_join, sst));
     }
-    // The value index needs the page scan only.  In a batch without strings their stream is idle: the index runs there,
-    // beside the bools and the row offsets (nested columns: three launches shorter on the main stream).
-    const bool vidx_side = overlap && !n_sreg && n_lreg && !pl->row_chunks.empty();
+    // The value index needs the page scan only.  It runs beside the bools and the row offsets on a stream that is idle by
+    // then: the strings' in a batch without strings (nested columns: three launches shorter on the main stream), else the
+    // gather's, which ends long before the level decode, when the main stream is the longer one (it saves the main stream
+    // a launch and costs the step a join: wide columns 1.483 -> 1.44 ms, the batch of all column kinds, where the string
+    // pass ends last either way, 3.395 -> 3.401 ms).  The two streams' lengths are estimated from the kernels' rates
+    // alone: 21 ns per 4 KiB of level bytes, 3.5 ns per row tile, 7.7 ns per string unit.  PQD_VIDX_SIDE=0 / 1 decides
+    // for every batch with strings instead.
+    static const int vidx_env = getenv("PQD_VIDX_SIDE") ? atoi(getenv("PQD_VIDX_SIDE")) : -1;
+    const double main_ns = 21.0 * pl->n_lvtiles * (pl->lv_tile / 4096.0) + 3.5 * pl->n_rtiles, str_ns = 7.7 * pl->schain.n_units;
+    const bool vidx_with_strings = vidx_env >= 0 ? vidx_env != 0 : main_ns > str_ns;
+    const bool vidx_side = overlap && (!n_sreg || vidx_with_strings) && n_lreg && !pl->row_chunks.empty();
+    hipStream_t vst = n_sreg ? ctx->stream3 : ctx->stream2;
     if (vidx_side) {
         HIP_TRY(ctx, hipEventRecord(pl->ev_levels, st));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, pl->ev_levels, 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(vst, pl->ev_levels, 0));
     }
     // the row offsets need the bitmaps of the level decode and nothing else: the longest kernel of this stream goes first
     // (the value index beside it when the strings' stream is idle, else behind it)
     if (ctx->rows_first && !vidx_side)
         HIP_TRY(ctx, launch_rows(st, pl->d_chunks, pl->d_rtile_prefix, pl->d_rtile_owner, pl->d_row_chunks, (u32)pl->row_chunks.size(), pl->n_rtiles,
                                  pl->d_row_tiles, pl->d_chunk_dyn));
-    HIP_TRY(ctx, launch_value_index(vidx_side ? ctx->stream2 : st, pl->d_chunks, pl->d_pages, pl->d_page_dyn, pl->d_vidx_pages,
+    HIP_TRY(ctx, launch_value_index(vidx_side ? vst : st, pl->d_chunks, pl->d_pages, pl->d_page_dyn, pl->d_vidx_pages,
                                     (u32)pl->vidx_pages.size(), pl->d_lvl_off));
-    if (vidx_side) HIP_TRY(ctx, hipEventRecord(pl->ev_join, ctx->stream2));
+    if (vidx_side) HIP_TRY(ctx, hipEventRecord(pl->ev_vidx, vst));
     HIP_TRY(ctx, launch_bools(st, src, pl->d_pages, pl->d_bool_pages, pl->d_btile_prefix, pl->d_btile_owner, (u32)pl->bool_pages.size(), pl->n_btiles,
                               pl->d_chunks, pl->d_page_dyn, pl->d_status));
     if (!ctx->rows_first || vidx_side)
@@ -952,7 +964,7 @@ static int enqueue_run(pqd_plan* pl, const u8* src, hipEvent_t ev_c0, hipEvent_t
         if (str_early) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join, 0));
         HIP_TRY(ctx, launch_str_check(st, pl->d_pages, pl->d_chunks, pl->d_page_dyn, pl->d_sregions, n_sreg, pl->d_stotals, pl->d_status));
     }
-    if (vidx_side) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join, 0));
+    if (vidx_side) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_vidx, 0));
     if (copy_side) HIP_TRY(ctx, hipStreamWaitEvent(st, pl->ev_join_copy, 0));
     return PQD_OK;
 }
