@@ -490,15 +490,18 @@ int pqd_plan_create(pqd_ctx* ctx, const pqd_chunk_desc* chunks, size_t n_chunks,
         want(PQD_OUT_PAGE_NONNULL, (size_t)C.n_pages * 8);
     }
 
-    // regions.  Super-tile size of the level decode: the 8 KiB build unless the batch is large (see pqd_device.h)
+    // regions.  Super-tile size of the level decode (see pqd_device.h): the 8 KiB build when the batch is bound by the chain of
+    // hand-overs inside its longest block, i.e. when all its super-tiles together are fewer than LV_CHAIN_RATIO times those
+    // of that block; else the 4 KiB build
     {
-        u64 n8 = 0;
+        u64 n8 = 0, longest = 1;
         for (size_t pi = 0; pi < n_pages; pi++)
             for (int lv = 0; lv < 2; lv++) {
                 const u32 nb = lv == 0 ? rep_bytes[pi] : def_bytes[pi];
-                if (nb) n8 += nb > 4 ? ((u64)nb - 4 + LV_T_SMALL_BATCH - 1) / LV_T_SMALL_BATCH : 1;
+                const u64 t = nb > 4 ? ((u64)nb - 4 + LV_T_SMALL_BATCH - 1) / LV_T_SMALL_BATCH : 1;
+                if (nb) { n8 += t; longest = std::max(longest, t); }
             }
-        pl->lv_tile = n8 > LV_LARGE_BATCH_TILES ? LV_T_LARGE_BATCH : LV_T_SMALL_BATCH;
+        pl->lv_tile = n8 > LV_CHAIN_RATIO * longest ? LV_T_LARGE_BATCH : LV_T_SMALL_BATCH;
         const char* force = getenv("PQD_LV_TILE");  // diagnostics: 4096 or 8192
         if (force && (atoi(force) == (int)LV_T_LARGE_BATCH || atoi(force) == (int)LV_T_SMALL_BATCH)) pl->lv_tile = (u32)atoi(force);
     }

@@ -201,7 +201,12 @@ hipError_t launch_levels_expand(hipStream_t st, int esz, const u8* src, const Re
 constexpr u32 LV_T = PQD_LV_TILE_BYTES;   // chain bytes per super-tile in this translation unit
 constexpr u32 LV_THREADS = LV_T / 16;     // one 16-byte sub-tile per thread
 constexpr u32 LV_T_SMALL_BATCH = 8192, LV_T_LARGE_BATCH = 4096;
-constexpr u32 LV_LARGE_BATCH_TILES = 1000;  // a batch of more 8 KiB super-tiles than this takes the 4 KiB build (optional int32, 10 % nulls: 608 super-tiles 71 vs 73 us, 1216: 104 vs 98 us, 2432: 177 vs 146 us)
+// A batch whose 8 KiB super-tiles are more than this many times those of its longest block takes the 4 KiB build: below that the
+// step waits for the hand-over chain of the longest block, which 8 KiB super-tiles halve.  Measured (4 KiB against 8 KiB, ms):
+// optional int32, blocks of 16 super-tiles: 4 blocks 0.097 / 0.087, 16: 0.108 / 0.097, 32: 0.116 / 0.127, 64: 0.150 / 0.176;
+// nested columns (longest block a fifth of a page's): ratio 3: 0.179 / 0.142, 12: 0.189 / 0.162, 49: 0.294 / 0.316;
+// nine column kinds, ratio 25: 0.413 / 0.400, 50: 0.526 / 0.571; optional strings, 32 blocks: 0.551 / 0.574.
+constexpr u32 LV_CHAIN_RATIO = 28;
 constexpr u32 LV_SUB = LV_T / LV_THREADS;
 constexpr unsigned long long LV_WAIT_TICKS = 200000000ull;  // a workgroup waits this long (100 MHz wall clock: 2 s) for a granule, then gives up
 struct LvTile { u32 region, index; };  // launch order: super-tile `index` of `region`; predecessors come first

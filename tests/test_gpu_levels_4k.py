@@ -1,5 +1,5 @@
 """The level decoder is built twice: 8 KiB super-tiles for small batches, 4 KiB super-tiles for large ones (the
-planner picks by the number of super-tiles).  The files of the other parity tests are small, so they run the 8 KiB
+planner picks by the batch's super-tiles against those of its longest block).  The files of the other parity tests hold few level blocks, so most of them run the 8 KiB
 build; here the same kinds of input go through the 4 KiB build (forced with PQD_LV_TILE, which the planner reads
 when a plan is created), and one batch large enough to select it by itself."""
 import os
@@ -78,7 +78,8 @@ def test_long_runs_across_super_tiles(ctx, small_tiles):
 
 
 def test_a_large_batch_selects_the_small_tiles_by_itself(ctx):
-    """More super-tiles of 8 KiB than the planner gives to the 8 KiB build (1000): 112 pages of 1M optional levels (128 KB of level bytes each)."""
+    """More level blocks than the planner gives to the 8 KiB build (the batch's super-tiles are more than 28 times those of its longest
+    block): 112 pages of 1M optional levels (128 KB of level bytes each)."""
     buf, ex = bench.build_file("optint", list(range(7)), 16, 1_000_000)
     pf = R.ParquetFile(buf)
     chunks, nc, pgs, npg = pf.descriptors(0, pf.num_row_groups)
