@@ -2840,43 +2840,53 @@ __global__ __launch_bounds__(256) void k_rows(const ChunkRec* __restrict__ chunk
 __global__ __launch_bounds__(256) void k_rows_scan(const ChunkRec* __restrict__ chunks, const u32* __restrict__ rtile_prefix,
                                                    const u32* __restrict__ chunk_ids, u32 n_rchunks,
                                                    RowTile* __restrict__ tiles, ChunkDyn* __restrict__ chunk_dyn) {
-    __shared__ u64 s_r[4], s_v[4];
+    __shared__ u32 s_r[2][4], s_v[2][4];
     const u32 k = blockIdx.x;
     if (k >= n_rchunks) return;
     const u32 c = chunk_ids[k];
     const ChunkRec C = chunks[c];
-    // every thread owns a contiguous slice of the chunk's tiles: slice sums, block scan, slice bases (four waves: a
-    // larger workgroup waits long for room on one CU while the long kernels of the other streams run)
+    // 256 tiles of the chunk per round, one per thread, and the counts of NR rounds asked for together: a thread that went
+    // through a slice of its own one tile after the other made 27 trips to memory, twice, for a chunk of 7000 tiles.
+    // Per round a scan over the workgroup (four waves: a larger workgroup waits long for room on one CU while the long
+    // kernels of the other streams run) on top of the totals of the rounds before.
+    constexpr u32 NR = 16;
     const u32 t0 = rtile_prefix[k], t1 = rtile_prefix[k + 1];
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 per = (t1 - t0 + 255) / 256;
-    const u32 a = t0 + tid * per < t1 ? t0 + tid * per : t1, b = a + per < t1 ? a + per : t1;
-    u64 r = 0, v = 0;
-    for (u32 t = a; t < b; t++) { r += tiles[t].rows; v += tiles[t].vals; }
-    u64 sr = r, sv = v;
-    for (int d = 1; d < 64; d <<= 1) {
-        const u64 tr = __shfl_up(sr, d), tv = __shfl_up(sv, d);
-        if (lane >= (u32)d) { sr += tr; sv += tv; }
-    }
-    if (lane == 63) { s_r[wv] = sr; s_v[wv] = sv; }
-    __syncthreads();
-    u64 base_r = 0, base_v = 0, tot_r = 0, tot_v = 0;
-    for (u32 q = 0; q < 4; q++) {
-        if (q < wv) { base_r += s_r[q]; base_v += s_v[q]; }
-        tot_r += s_r[q]; tot_v += s_v[q];
-    }
-    u64 run_r = base_r + sr - r, run_v = base_v + sv - v;
-    for (u32 t = a; t < b; t++) {
-        const u32 tr = tiles[t].rows, tv = tiles[t].vals;
-        tiles[t].row_base = run_r;
-        tiles[t].val_base = run_v;
-        run_r += tr;
-        run_v += tv;
+    u64 run_r = 0, run_v = 0;
+    u32 par = 0;  // the partial sums of consecutive rounds go to alternate slots: one barrier a round
+    for (u32 g0 = t0; g0 < t1; g0 += 256 * NR) {
+        u32 rr[NR], vv[NR];
+#pragma unroll
+        for (u32 q = 0; q < NR; q++) {
+            const u32 t = g0 + q * 256 + tid;
+            rr[q] = t < t1 ? tiles[t].rows : 0;  // at most RT each: a workgroup's sums fit 32 bits
+            vv[q] = t < t1 ? tiles[t].vals : 0;
+        }
+#pragma unroll
+        for (u32 q = 0; q < NR; q++) {
+            if (g0 + q * 256 >= t1) break;  // the same for all threads
+            const u32 t = g0 + q * 256 + tid;
+            const u32 sr = sf_wave_scan(rr[q]), sv = sf_wave_scan(vv[q]);
+            if (lane == 63) { s_r[par][wv] = sr; s_v[par][wv] = sv; }
+            __syncthreads();
+            u32 br = 0, bv = 0, tr = 0, tv = 0;
+            for (u32 w = 0; w < 4; w++) {
+                if (w < wv) { br += s_r[par][w]; bv += s_v[par][w]; }
+                tr += s_r[par][w]; tv += s_v[par][w];
+            }
+            if (t < t1) {
+                tiles[t].row_base = run_r + br + sr - rr[q];
+                tiles[t].val_base = run_v + bv + sv - vv[q];
+            }
+            run_r += tr;
+            run_v += tv;
+            par ^= 1;
+        }
     }
     if (tid == 0) {
-        chunk_dyn[c].n_rows = tot_r;
-        if (!C.shares_rep) ((int32_t*)C.row_level_off)[tot_r] = (int32_t)C.n_levels;
-        ((int32_t*)C.row_value_off)[tot_r] = (int32_t)tot_v;
+        chunk_dyn[c].n_rows = run_r;
+        if (!C.shares_rep) ((int32_t*)C.row_level_off)[run_r] = (int32_t)C.n_levels;
+        ((int32_t*)C.row_value_off)[run_r] = (int32_t)run_v;
     }
 }
 
